@@ -1,0 +1,84 @@
+"""Seeded synthetic Gaussian scenes standing in for the datasets BASELINE.json names (there are no
+datasets or checkpoints in the build/bench environment).  Shapes and parameter ranges follow
+SURVEY.md §8d (C1..C5) and configs/initialization/random.yaml of the reference.
+
+All generators return *activated* parameters in the layout the tracer boundary consumes
+(threedgut_tracer/tracer.py:323-327): positions [N,3], rotation [N,4] (wxyz, unit), scale [N,3]
+(post-exp), density [N,1] (post-sigmoid), features [N,48] (coefficient-major: 16 x RGB).
+"""
+import math
+
+import numpy as np
+
+
+def _finish(rng, pos, log_scale, n, opacity_logit_std=1.5, opacity_logit_mean=0.0, sh_rest_std=0.1):
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    logit = rng.normal(opacity_logit_mean, opacity_logit_std, size=(n, 1))
+    dens = 1.0 / (1.0 + np.exp(-logit))
+    sph = np.zeros((n, 16, 3))
+    sph[:, 0, :] = rng.uniform(-1.0, 1.0, size=(n, 3))
+    sph[:, 1:, :] = rng.normal(0.0, sh_rest_std, size=(n, 15, 3))
+    return dict(
+        positions=pos.astype(np.float32), rotation=q.astype(np.float32),
+        scale=np.exp(log_scale).astype(np.float32), density=dens.astype(np.float32),
+        features=sph.reshape(n, 48).astype(np.float32),
+    )
+
+
+def scene_c1(n=1000, seed=0):
+    """C1: 1k random Gaussians in [-1,1]^3 (BASELINE configs[0])."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-1.0, 1.0, size=(n, 3))
+    ls = rng.uniform(math.log(0.02), math.log(0.2), size=(n, 3))
+    return _finish(rng, pos, ls, n)
+
+
+def scene_lego_like(n=300_000, seed=1):
+    """C2: NeRF-Synthetic-lego-like object scene, N in U[-1.3,1.3]^3, scales log-U[.003,.03]."""
+    rng = np.random.default_rng(seed)
+    # concentrate mass on a blocky object: half uniform in the box, half on a few slabs
+    n_slab = n // 2
+    pos = rng.uniform(-1.3, 1.3, size=(n, 3))
+    slab_axis = rng.integers(0, 3, size=n_slab)
+    slab_lvl = rng.choice(np.array([-0.6, -0.2, 0.2, 0.6]), size=n_slab)
+    pos[np.arange(n_slab), slab_axis] = slab_lvl + rng.normal(0, 0.01, size=n_slab)
+    pos[:n_slab] *= 0.7
+    ls = rng.uniform(math.log(0.003), math.log(0.03), size=(n, 3))
+    return _finish(rng, pos, ls, n)
+
+
+def scene_outdoor_like(n=6_000_000, seed=2, extent=12.0, n_blobs=64, ground_frac=0.35, scale_mu=math.log(0.01),
+                       scale_sigma=1.0):
+    """C3/C5: MipNeRF360-outdoor-like scene (bicycle / garden stand-in): a central object cluster,
+    a ground plane and a far shell, heavy-tailed (log-normal) scales.  World is right-down-front so
+    'down' is +y and the ground plane sits at y = +1."""
+    rng = np.random.default_rng(seed)
+    n_ground = int(n * ground_frac)
+    n_far = int(n * 0.15)
+    n_blob = n - n_ground - n_far
+    centers = rng.normal(0.0, 1.2, size=(n_blobs, 3)) * np.array([1.0, 0.35, 1.0])
+    sizes = rng.uniform(0.08, 0.6, size=(n_blobs, 1))
+    which = rng.integers(0, n_blobs, size=n_blob)
+    blob = centers[which] + rng.normal(size=(n_blob, 3)) * sizes[which]
+    r = extent * np.sqrt(rng.uniform(0.0, 1.0, size=n_ground))
+    a = rng.uniform(0, 2 * math.pi, size=n_ground)
+    ground = np.stack([r * np.cos(a), 1.0 + rng.normal(0, 0.02, size=n_ground), r * np.sin(a)], axis=1)
+    v = rng.normal(size=(n_far, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[:, 1] = -np.abs(v[:, 1])  # upper hemisphere (up is -y)
+    far = v * rng.uniform(extent, 3 * extent, size=(n_far, 1))
+    pos = np.concatenate([blob, ground, far], axis=0)
+    ls = rng.normal(scale_mu, scale_sigma, size=(n, 1)) + rng.normal(0, 0.35, size=(n, 3))
+    ls[n_blob + n_ground:] += math.log(8.0)  # far shell: larger splats
+    ls = np.clip(ls, math.log(5e-4), math.log(3.0))
+    perm = rng.permutation(n)
+    out = _finish(rng, pos, ls, n)
+    return {k: val[perm] for k, val in out.items()}
+
+
+def pack_density(scene):
+    """[N,12] particle_density as packed by _Autograd.forward (tracer.py:176-178)."""
+    n = scene["positions"].shape[0]
+    return np.concatenate([scene["positions"], scene["density"], scene["rotation"], scene["scale"],
+                           np.zeros((n, 1), np.float32)], axis=1).astype(np.float32)

@@ -1,0 +1,881 @@
+/*
+ * gut_oracle.c — CPU restatement of the reference's 3DGUT renderer (forward + backward).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (3dgrut_amd/, bench.py's timed GPU
+ * region) may link, load or call this file.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's `cpu_baseline` leg use it, and only as the checker.
+ *
+ * PARITY STATUS: "parity unpinned" for the device kernels — the reference holds no tests, golden
+ * images or known-answer vectors for this path, and its CUDA/Slang sources
+ * cannot be compiled here (no nvcc, no slangc, tiny-cuda-nn un-vendored).  This file restates the
+ * reference sources read as text; every function cites the reference file:line it follows.  The
+ * host-side pose math is pinned by tests/golden/pose_golden.npz (generated from the reference's
+ * own Python, see tests/golden/gen_pose_golden.py).
+ *
+ * Numerics contract shared with the HIP kernels (so that integer tile/key buffers are bit-exact):
+ *   - all arithmetic fp32, evaluated left-to-right as written, NO fused multiply-add
+ *     (compile with -ffp-contract=off);
+ *   - sqrtf and '/' are IEEE correctly rounded (true on x86-64 and in hipcc's default mode);
+ *   - logf / atan2f are NOT taken from libm (glibc and the ROCm device library differ in the last
+ *     ulp): both sides evaluate det_logf / det_atan2f_pos below (fdlibm- and Cephes-style
+ *     published algorithms, +,-,*,/ and integer ops only);
+ *   - float -> int conversions are clamped in the float domain first (the reference relies on
+ *     CUDA's saturating cvt, gutProjector.cuh:35-40).
+ * The reference itself is built with -use_fast_math (setup_3dgut.py:83), so not even two CUDA
+ * GPUs of different generations agree with each other bit-for-bit; the contract above is what
+ * "bit-exact" is defined against.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GUT_TILE 16
+#define GUT_BLOCK 256
+#define INVALID_IDX 0xFFFFFFFFu
+
+/* ---- render constants: configs/render/3dgut.yaml, configs/render/3dgrt.yaml, threedgut.cuh:32-88 ---- */
+typedef struct {
+    float alpha_threshold;        /* particle_kernel_min_alpha = 1/255          (3dgrt.yaml:8)  */
+    float max_alpha;              /* particle_kernel_max_alpha = 0.99           (3dgrt.yaml:9)  */
+    float min_kernel_density;     /* particle_kernel_min_response = 0.0113      (3dgut.yaml:9)  */
+    float min_transmittance;      /* min_transmittance = 1e-4                   (3dgut.yaml:10) */
+    float min_sensor_z;           /* ParticleMinSensorZ = 0.2                   (threedgut.cuh:49) */
+    float cov_dilation;           /* CovarianceDilation = 0.3                   (threedgut.cuh:50) */
+    float ut_alpha, ut_beta, ut_kappa; /* 1, 2, 0                               (3dgut.yaml:19-21) */
+    float ut_margin;              /* in_image_margin_factor = 0.1               (3dgut.yaml:22) */
+    int32_t rect_bounding, tight_opacity_bounding, tile_culling, global_z_order; /* all 1 */
+} OracleParams;
+
+typedef struct {
+    int32_t model;   /* 0 = OpenCV pinhole, 1 = OpenCV fisheye        (sensors/cameraModels.h:42-47) */
+    int32_t shutter; /* 4 = global; 0..3 rolling (unsupported here)   (sensors/cameraModels.h:34-40) */
+    float principal_point[2];
+    float focal_length[2];
+    float radial[6];      /* pinhole k1..k6; fisheye k1..k4 in radial[0..3] */
+    float tangential[2];
+    float thin_prism[4];
+    float max_angle;
+    float pose_start[7];  /* world->sensor: t(3), q(x,y,z,w)  (tracer.py:138-151, splatRaster.cpp:92-100) */
+    float pose_end[7];
+} OracleCamera;
+
+void oracle_default_params(OracleParams* p) {
+    p->alpha_threshold = 1.0f / 255.0f;
+    p->max_alpha = 0.99f;
+    p->min_kernel_density = 0.0113f;
+    p->min_transmittance = 0.0001f;
+    p->min_sensor_z = 0.2f;
+    p->cov_dilation = 0.3f;
+    p->ut_alpha = 1.0f; p->ut_beta = 2.0f; p->ut_kappa = 0.0f;
+    p->ut_margin = 0.1f;
+    p->rect_bounding = 1; p->tight_opacity_bounding = 1; p->tile_culling = 1; p->global_z_order = 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * deterministic elementary functions (see header)
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* natural log for finite x > 0 (fdlibm e_logf.c algorithm, general branch) */
+static float det_logf(float x) {
+    uint32_t ix = f2u(x);
+    int k = 0;
+    if (ix >= 0x7f800000u) return x;                 /* inf / nan passthrough */
+    if (ix < 0x00800000u) {                          /* subnormal (or 0) */
+        if (ix == 0) return -INFINITY;
+        x = x * 33554432.0f; ix = f2u(x); k -= 25;
+    }
+    k += (int)(ix >> 23) - 127;
+    ix &= 0x007fffffu;
+    uint32_t i = (ix + (0x95f64u << 3)) & 0x800000u;
+    x = u2f(ix | (i ^ 0x3f800000u));
+    k += (int)(i >> 23);
+    const float f = x - 1.0f;
+    const float s = f / (2.0f + f);
+    const float dk = (float)k;
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * (0.40000972152f + w * 0.24279078841f);
+    const float t2 = z * (0.66666662693f + w * 0.28498786688f);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    return dk * 6.9313812256e-01f - ((hfsq - (s * (hfsq + R) + dk * 9.0580006145e-06f)) - f);
+}
+
+/* atan2(y, x) for y > 0 (Cephes atanf range reduction + polynomial); result in (0, pi) */
+static float det_atan2f_pos(float y, float x) {
+    const float ax = fabsf(x);
+    const float lo = y < ax ? y : ax;
+    const float hi = y < ax ? ax : y;
+    float t = lo / hi;                               /* in [0,1] */
+    float base = 0.0f;
+    if (t > 0.4142135679721832f) { base = 0.7853981852531433f; t = (t - 1.0f) / (t + 1.0f); }
+    const float z = t * t;
+    float a = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
+    a = base + a;
+    if (y > ax) a = 1.5707963705062866f - a;
+    if (x < 0.0f) a = 3.1415927410125732f - a;
+    return a;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * host-side pose math (float)
+ * tiny-cuda-nn is not vendored: to_mat3 / quat(mat3) / slerp / mix are restated with
+ * their GLM-equivalent textbook definitions, column-major, quaternion ctor (w,x,y,z).
+ * Call sites: sensors/sensors.h:44-73, gutRenderer.cu:266-284.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float c[3][3]; } M3; /* c[col][row] */
+
+static M3 quat_to_mat3(float w, float x, float y, float z) {
+    M3 m;
+    const float qxx = x * x, qyy = y * y, qzz = z * z;
+    const float qxz = x * z, qxy = x * y, qyz = y * z;
+    const float qwx = w * x, qwy = w * y, qwz = w * z;
+    m.c[0][0] = 1.0f - 2.0f * (qyy + qzz); m.c[0][1] = 2.0f * (qxy + qwz); m.c[0][2] = 2.0f * (qxz - qwy);
+    m.c[1][0] = 2.0f * (qxy - qwz); m.c[1][1] = 1.0f - 2.0f * (qxx + qzz); m.c[1][2] = 2.0f * (qyz + qwx);
+    m.c[2][0] = 2.0f * (qxz + qwy); m.c[2][1] = 2.0f * (qyz - qwx); m.c[2][2] = 1.0f - 2.0f * (qxx + qyy);
+    return m;
+}
+
+/* interpolatedSensorPose(start, end, 0.5), sensors/sensors.h:55-68 (slerp + mix) */
+static void interpolate_pose(const float* a, const float* b, float t, float* out) {
+    float qa[4] = {a[6], a[3], a[4], a[5]}; /* w,x,y,z */
+    float qb[4] = {b[6], b[3], b[4], b[5]};
+    float cosT = qa[0] * qb[0] + qa[1] * qb[1] + qa[2] * qb[2] + qa[3] * qb[3];
+    if (cosT < 0.0f) { for (int i = 0; i < 4; ++i) qb[i] = -qb[i]; cosT = -cosT; }
+    float q[4];
+    if (cosT > 1.0f - 1.1920929e-07f) {
+        for (int i = 0; i < 4; ++i) q[i] = qa[i] * (1.0f - t) + qb[i] * t;
+    } else {
+        const float ang = acosf(cosT);
+        const float s0 = sinf((1.0f - t) * ang), s1 = sinf(t * ang), sd = sinf(ang);
+        for (int i = 0; i < 4; ++i) q[i] = (s0 * qa[i] + s1 * qb[i]) / sd;
+    }
+    for (int i = 0; i < 3; ++i) out[i] = a[i] * (1.0f - t) + b[i] * t;
+    out[3] = q[1]; out[4] = q[2]; out[5] = q[3]; out[6] = q[0];
+}
+
+typedef struct {
+    M3 Rs; float ts[3];      /* start pose world->sensor (projection of sigma points, cameraProjections.cuh:154-157) */
+    M3 Rm; float tm[3];      /* mid pose world->sensor (depth key, gutProjector.cuh:137,317) */
+    M3 Rinv; float cam[3];   /* sensor->world (ray transform rayPayload.cuh:93-94) and sensor world position */
+} PoseSet;
+
+static PoseSet make_pose_set(const OracleCamera* cam) {
+    PoseSet p;
+    const float* s = cam->pose_start;
+    p.Rs = quat_to_mat3(s[6], s[3], s[4], s[5]);
+    p.ts[0] = s[0]; p.ts[1] = s[1]; p.ts[2] = s[2];
+    float mid[7];
+    interpolate_pose(cam->pose_start, cam->pose_end, 0.5f, mid);
+    p.Rm = quat_to_mat3(mid[6], mid[3], mid[4], mid[5]);
+    p.tm[0] = mid[0]; p.tm[1] = mid[1]; p.tm[2] = mid[2];
+    /* sensorPoseInverse (sensors.h:44-53): R^T and -R^T t.  The reference round-trips R^T through
+     * a quaternion (tcnn::quat{mat3}) and back; that only adds rounding noise and is skipped. */
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) p.Rinv.c[c][r] = p.Rm.c[r][c];
+    for (int r = 0; r < 3; ++r)
+        p.cam[r] = -1.0f * (p.Rinv.c[0][r] * p.tm[0] + p.Rinv.c[1][r] * p.tm[1] + p.Rinv.c[2][r] * p.tm[2]);
+    return p;
+}
+
+/* exported for the pose tests: world->sensor (t,q xyzw) -> 3x4 matrices, row-major [3][4] */
+void oracle_pose_matrices(const OracleCamera* cam, float* w2s_start, float* w2s_mid, float* s2w) {
+    PoseSet p = make_pose_set(cam);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            w2s_start[r * 4 + c] = p.Rs.c[c][r];
+            w2s_mid[r * 4 + c] = p.Rm.c[c][r];
+            s2w[r * 4 + c] = p.Rinv.c[c][r];
+        }
+        w2s_start[r * 4 + 3] = p.ts[r];
+        w2s_mid[r * 4 + 3] = p.tm[r];
+        s2w[r * 4 + 3] = p.cam[r];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * camera projections — sensors/cameraProjections.cuh:52-128
+ * ---------------------------------------------------------------------------------------------- */
+static int within_resolution(float rx, float ry, float tol, float px, float py) {
+    const float mx = rx * tol, my = ry * tol;
+    return (px > -mx) && (py > -my) && (px < rx + mx) && (py < ry + my);
+}
+
+static int project_pinhole(const OracleCamera* c, int W, int H, const float p[3], float tol, float out[2]) {
+    if (p[2] <= 0.0f) { out[0] = 0.0f; out[1] = 0.0f; return 0; }
+    const float u = p[0] / p[2], v = p[1] / p[2];
+    const float u2 = u * u, v2 = v * v;
+    const float r2 = u2 + v2;
+    const float a1 = 2.0f * u * v;
+    const float a2 = r2 + 2.0f * u2;
+    const float a3 = r2 + 2.0f * v2;
+    const float num = 1.0f + r2 * (c->radial[0] + r2 * (c->radial[1] + r2 * c->radial[2]));
+    const float den = 1.0f + r2 * (c->radial[3] + r2 * (c->radial[4] + r2 * c->radial[5]));
+    const float icD = num / den;
+    const float dx = c->tangential[0] * a1 + c->tangential[1] * a2 + r2 * (c->thin_prism[0] + r2 * c->thin_prism[1]);
+    const float dy = c->tangential[0] * a3 + c->tangential[1] * a1 + r2 * (c->thin_prism[2] + r2 * c->thin_prism[3]);
+    const float und_x = icD * u + dx, und_y = icD * v + dy;
+    const int valid_radial = (icD > 0.8f) && (icD < 1.2f);
+    if (valid_radial) {
+        out[0] = und_x * c->focal_length[0] + c->principal_point[0];
+        out[1] = und_y * c->focal_length[1] + c->principal_point[1];
+    } else {
+        /* hypotf(W,H) restated as sqrtf(W*W+H*H) (deterministic; same value for image-sized ints) */
+        const float fw = (float)W, fh = (float)H;
+        const float clip = sqrtf(fw * fw + fh * fh);
+        const float k = clip / sqrtf(r2);
+        out[0] = k * u + c->principal_point[0];
+        out[1] = k * v + c->principal_point[1];
+    }
+    return valid_radial && within_resolution((float)W, (float)H, tol, out[0], out[1]);
+}
+
+static int project_fisheye(const OracleCamera* c, int W, int H, const float p[3], float tol, float out[2]) {
+    const float eps = 1.1920929e-07f;
+    float rho = sqrtf(p[0] * p[0] + p[1] * p[1]);
+    rho = rho > eps ? rho : eps;
+    const float theta_full = det_atan2f_pos(rho, p[2]);
+    const float theta = theta_full < c->max_angle ? theta_full : c->max_angle;
+    const float t2 = theta * theta;
+    /* evalPolyHorner<4>(radialCoeffs, theta2): y = c3; y = x*y + c_i */
+    float poly = c->radial[3];
+    poly = t2 * poly + c->radial[2];
+    poly = t2 * poly + c->radial[1];
+    poly = t2 * poly + c->radial[0];
+    const float delta = (theta * (poly * t2 + 1.0f)) / rho;
+    out[0] = c->focal_length[0] * p[0] * delta + c->principal_point[0];
+    out[1] = c->focal_length[1] * p[1] * delta + c->principal_point[1];
+    return (theta < c->max_angle) && within_resolution((float)W, (float)H, tol, out[0], out[1]);
+}
+
+/* projectPointWithShutter, global-shutter branch (cameraProjections.cuh:146-160) */
+static int project_world_point(const OracleCamera* c, const PoseSet* ps, int W, int H, const float w[3], float tol, float out[2]) {
+    float p[3];
+    for (int r = 0; r < 3; ++r)
+        p[r] = ps->Rs.c[0][r] * w[0] + ps->Rs.c[1][r] * w[1] + ps->Rs.c[2][r] * w[2] + ps->ts[r];
+    if (c->model == 0) return project_pinhole(c, W, H, p, tol, out);
+    if (c->model == 1) return project_fisheye(c, W, H, p, tol, out);
+    out[0] = 0.0f; out[1] = 0.0f;
+    return 0;
+}
+
+/* quaternion (w,x,y,z) -> rows of rotationT — slang/common/transforms.slang:22-39 */
+static void quat_to_rows(const float q[4], float r[3][3]) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, xz = x * z, yz = y * z;
+    const float rx = w * x, ry = w * y, rz = w * z;
+    r[0][0] = 1.0f - 2.0f * (yy + zz); r[0][1] = 2.0f * (xy + rz); r[0][2] = 2.0f * (xz - ry);
+    r[1][0] = 2.0f * (xy - rz); r[1][1] = 1.0f - 2.0f * (xx + zz); r[1][2] = 2.0f * (yz + rx);
+    r[2][0] = 2.0f * (xz + ry); r[2][1] = 2.0f * (yz - rx); r[2][2] = 1.0f - 2.0f * (xx + yy);
+}
+
+/* SH basis Y_k(dir), k<16 — models/gaussianParticles.cuh:57-96 (same constants/signs as 3DGS) */
+static void sh_basis(int deg, const float d[3], float Y[16]) {
+    for (int i = 0; i < 16; ++i) Y[i] = 0.0f;
+    Y[0] = 0.28209479177387814f;
+    if (deg > 0) {
+        const float x = d[0], y = d[1], z = d[2];
+        Y[1] = -0.4886025119029199f * y; Y[2] = 0.4886025119029199f * z; Y[3] = -0.4886025119029199f * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            Y[4] = 1.0925484305920792f * xy;
+            Y[5] = -1.0925484305920792f * yz;
+            Y[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+            Y[7] = -1.0925484305920792f * xz;
+            Y[8] = 0.5462742152960396f * (xx - yy);
+            if (deg > 2) {
+                Y[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
+                Y[10] = 2.890611442640554f * xy * z;
+                Y[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+                Y[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                Y[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+                Y[14] = 1.445305721320277f * z * (xx - yy);
+                Y[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * tile helpers — gutProjector.cuh:32-78
+ * ---------------------------------------------------------------------------------------------- */
+static int clamp_tile(float v, int grid) {
+    /* min(grid, max(0, (int)v)) with the clamp done in float (saturating-cvt semantics) */
+    if (!(v > 0.0f)) return 0;                /* also NaN -> 0 */
+    if (v >= (float)grid) return grid;
+    return (int)v;
+}
+
+static void tile_bbox(int gx, int gy, const float pos[2], const float ext[2], int bmin[2], int bmax[2]) {
+    bmin[0] = clamp_tile(floorf((pos[0] - 0.5f - ext[0]) / 16.0f), gx);
+    bmin[1] = clamp_tile(floorf((pos[1] - 0.5f - ext[1]) / 16.0f), gy);
+    bmax[0] = clamp_tile(ceilf((pos[0] - 0.5f + ext[0]) / 16.0f), gx);
+    bmax[1] = clamp_tile(ceilf((pos[1] - 0.5f + ext[1]) / 16.0f), gy);
+}
+
+static float saturatef(float v) { return v > 0.0f ? (v < 1.0f ? v : 1.0f) : 0.0f; }
+
+/* tileMinParticlePowerResponse, gutProjector.cuh:49-78 */
+static float tile_min_power(float tx, float ty, const float conic[4], const float mean[2]) {
+    const float ts = 16.0f;
+    const float tminx = ts * tx, tminy = ts * ty;
+    const float tmaxx = ts + tminx, tmaxy = ts + tminy;
+    const float offx = tminx - mean[0], offy = tminy - mean[1];
+    const float lax = offx > 0.0f ? 1.0f : 0.0f, lay = offy > 0.0f ? 1.0f : 0.0f;
+    const float nrx = lax + (mean[0] > tmaxx ? 1.0f : 0.0f);
+    const float nry = lay + (mean[1] > tmaxy ? 1.0f : 0.0f);
+    if ((nrx + nry) > 0.0f) {
+        const float px = lax > 0.0f ? tminx : tmaxx;
+        const float py = lay > 0.0f ? tminy : tmaxy;
+        const float dxx = copysignf(ts, offx), dxy = copysignf(ts, offy);
+        const float dfx = mean[0] - px, dfy = mean[1] - py;
+        const float rcx = 1.0f / (ts * ts * conic[0]);
+        const float rcy = 1.0f / (ts * ts * conic[2]);
+        const float tx_ = nry * saturatef((dxx * conic[0] * dfx + dxx * conic[1] * dfy) * rcx);
+        const float ty_ = nrx * saturatef((dxy * conic[1] * dfx + dxy * conic[2] * dfy) * rcy);
+        const float mx = mean[0] - (px + tx_ * dxx);
+        const float my = mean[1] - (py + ty_ * dxy);
+        return 0.5f * (conic[0] * mx * mx + conic[2] * my * my) + conic[1] * mx * my;
+    }
+    return 0.0f;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K1: projectOnTiles — gutProjector.cuh:81-322
+ * Outputs per Gaussian: tiles_count, proj_pos(2), conic_opacity(4), extent(2), depth, feat(3), visibility.
+ * Deviation: visibility := validProjection && validConic (the reference reads
+ * an uninitialised covariance for culled Gaussians).
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_project(const OracleParams* prm, const OracleCamera* cam, int W, int H, uint32_t N, int sh_degree,
+                    const float* density12, const float* sph48,
+                    uint32_t* tiles_count, float* proj_pos, float* conic_opacity, float* extent,
+                    float* depth, float* feat, int32_t* visibility) {
+    const PoseSet ps = make_pose_set(cam);
+    const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
+    const float D = 3.0f;
+    const float lambda = prm->ut_alpha * prm->ut_alpha * (D + prm->ut_kappa) - D;
+    const float delta_f = sqrtf(prm->ut_alpha * prm->ut_alpha * (D + prm->ut_kappa)); /* GAUSSIAN_UT_DELTA, setup_3dgut.py:41-45 */
+    const float w0_mean = lambda / (D + lambda);
+    const float wi = 1.0f / (2.0f * (D + lambda));
+    const float w0_cov = lambda / (D + lambda) + (1.0f - prm->ut_alpha * prm->ut_alpha + prm->ut_beta);
+
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t ii = 0; ii < (int64_t)N; ++ii) {
+        const uint32_t i = (uint32_t)ii;
+        const float* g = density12 + (size_t)i * 12;
+        const float pos[3] = {g[0], g[1], g[2]};
+        const float opacity_in = g[3];
+        const float quat[4] = {g[4], g[5], g[6], g[7]};
+        const float scl[3] = {g[8], g[9], g[10]};
+
+        tiles_count[i] = 0;
+        proj_pos[2 * i] = 0.0f; proj_pos[2 * i + 1] = 0.0f;
+        for (int k = 0; k < 4; ++k) conic_opacity[4 * i + k] = 0.0f;
+        extent[2 * i] = 0.0f; extent[2 * i + 1] = 0.0f;
+        depth[i] = 0.0f;
+        feat[3 * i] = 0.0f; feat[3 * i + 1] = 0.0f; feat[3 * i + 2] = 0.0f;
+        visibility[i] = 0;
+
+        /* unscentedParticleProjection, gutProjector.cuh:118-215 */
+        if (opacity_in < prm->alpha_threshold) continue;
+        const float zcam = pos[0] * ps.Rm.c[0][2] + pos[1] * ps.Rm.c[1][2] + pos[2] * ps.Rm.c[2][2] + ps.tm[2];
+        if (zcam < prm->min_sensor_z) continue;
+
+        float rows[3][3];
+        quat_to_rows(quat, rows);
+        float sig[7][2];
+        int nvalid = 0;
+        nvalid += project_world_point(cam, &ps, W, H, pos, prm->ut_margin, sig[0]);
+        float cx = sig[0][0] * w0_mean, cy = sig[0][1] * w0_mean;
+        for (int a = 0; a < 3; ++a) {
+            const float k = delta_f * scl[a];
+            const float d[3] = {k * rows[a][0], k * rows[a][1], k * rows[a][2]};
+            const float pp[3] = {pos[0] + d[0], pos[1] + d[1], pos[2] + d[2]};
+            const float pm[3] = {pos[0] - d[0], pos[1] - d[1], pos[2] - d[2]};
+            nvalid += project_world_point(cam, &ps, W, H, pp, prm->ut_margin, sig[a + 1]);
+            cx += wi * sig[a + 1][0]; cy += wi * sig[a + 1][1];
+            nvalid += project_world_point(cam, &ps, W, H, pm, prm->ut_margin, sig[a + 4]);
+            cx += wi * sig[a + 4][0]; cy += wi * sig[a + 4][1];
+        }
+        if (nvalid == 0) continue;
+        float cov[3];
+        {
+            const float ex = sig[0][0] - cx, ey = sig[0][1] - cy;
+            cov[0] = w0_cov * (ex * ex); cov[1] = w0_cov * (ex * ey); cov[2] = w0_cov * (ey * ey);
+        }
+        for (int k = 0; k < 6; ++k) {
+            const float ex = sig[k + 1][0] - cx, ey = sig[k + 1][1] - cy;
+            cov[0] += wi * (ex * ex); cov[1] += wi * (ex * ey); cov[2] += wi * (ey * ey);
+        }
+
+        /* computeProjectedExtentConicOpacity, gutProjector.cuh:81-116 */
+        const float dcx = cov[0] + prm->cov_dilation, dcy = cov[1], dcz = cov[2] + prm->cov_dilation;
+        const float ddet = dcx * dcz - dcy * dcy;
+        if (ddet == 0.0f) continue;
+        float con[4];
+        con[0] = dcz / ddet; con[1] = -dcy / ddet; con[2] = dcx / ddet;
+        const float cdet = cov[0] * cov[2] - cov[1] * cov[1];
+        const float ratio = cdet / ddet;
+        const float conv = sqrtf(ratio > 0.000025f ? ratio : 0.000025f); /* fmaxf(0.000025, ratio); NaN -> 0.000025 */
+        con[3] = opacity_in * conv;
+        if (con[3] < prm->alpha_threshold) continue;
+        const float max_power = det_logf(con[3] / prm->alpha_threshold);
+        float extent_factor = 3.33f;
+        if (prm->tight_opacity_bounding) {
+            const float e = sqrtf(2.0f * max_power);
+            extent_factor = e < 3.33f ? e : 3.33f;
+        }
+        const float mid = 0.5f * (dcx + dcz);
+        const float disc = mid * mid - ddet;
+        const float lam = mid + sqrtf(disc > 0.01f ? disc : 0.01f); /* fmaxf(0.01, disc) */
+        const float radius = extent_factor * sqrtf(lam);
+        float ext[2];
+        if (prm->rect_bounding) {
+            const float ex = extent_factor * sqrtf(dcx), ey = extent_factor * sqrtf(dcz);
+            ext[0] = ex < radius ? ex : radius; ext[1] = ey < radius ? ey : radius;
+        } else { ext[0] = radius; ext[1] = radius; }
+        if (!(radius > 0.0f)) continue;
+
+        visibility[i] = 1;
+
+        /* tile count with per-tile culling, gutProjector.cuh:279-293 */
+        const float mean2[2] = {cx, cy};
+        int bmin[2], bmax[2];
+        tile_bbox(gx, gy, mean2, ext, bmin, bmax);
+        uint32_t cnt = 0;
+        if (prm->tile_culling) {
+            for (int y = bmin[1]; y < bmax[1]; ++y)
+                for (int x = bmin[0]; x < bmax[0]; ++x)
+                    if (tile_min_power((float)x, (float)y, con, mean2) < max_power) cnt++;
+        } else {
+            cnt = (uint32_t)((bmax[0] - bmin[0]) * (bmax[1] - bmin[1]));
+        }
+        tiles_count[i] = cnt;
+        if (cnt == 0) continue;
+
+        /* precomputed view-dependent RGB (unclamped), gutProjector.cuh:304-310 */
+        const float sr[3] = {pos[0] - ps.cam[0], pos[1] - ps.cam[1], pos[2] - ps.cam[2]};
+        const float dist = sqrtf(sr[0] * sr[0] + sr[1] * sr[1] + sr[2] * sr[2]);
+        const float dir[3] = {sr[0] / dist, sr[1] / dist, sr[2] / dist};
+        float Y[16];
+        sh_basis(sh_degree, dir, Y);
+        const int ncoef = (sh_degree + 1) * (sh_degree + 1);
+        const float* sh = sph48 + (size_t)i * 48;
+        for (int ch = 0; ch < 3; ++ch) {
+            float acc = 0.0f;
+            for (int k = 0; k < ncoef; ++k) acc += Y[k] * sh[3 * k + ch];
+            feat[3 * i + ch] = acc + 0.5f;
+        }
+        proj_pos[2 * i] = cx; proj_pos[2 * i + 1] = cy;
+        for (int k = 0; k < 4; ++k) conic_opacity[4 * i + k] = con[k];
+        extent[2 * i] = ext[0]; extent[2 * i + 1] = ext[1];
+        depth[i] = prm->global_z_order ? zcam : dist;
+    }
+}
+
+/* K2: inclusive scan — gutRenderer.cu:302-310 */
+uint32_t oracle_scan(uint32_t N, const uint32_t* count, uint32_t* offset) {
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < N; ++i) { acc += count[i]; offset[i] = acc; }
+    return acc;
+}
+
+/* K3: expandTileProjections — gutProjector.cuh:324-388 */
+void oracle_expand(const OracleParams* prm, int W, int H, uint32_t N,
+                   const uint32_t* offset, const float* proj_pos, const float* conic_opacity,
+                   const float* extent, const float* depth, uint64_t* keys, uint32_t* ids) {
+    const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
+    for (uint32_t i = 0; i < N; ++i) {
+        const float ext[2] = {extent[2 * i], extent[2 * i + 1]};
+        if (ext[0] <= 1e-06f) continue;
+        const uint32_t dkey = f2u(depth[i]);
+        uint32_t off = (i == 0) ? 0 : offset[i - 1];
+        const uint32_t max_off = offset[i];
+        const float mean2[2] = {proj_pos[2 * i], proj_pos[2 * i + 1]};
+        int bmin[2], bmax[2];
+        tile_bbox(gx, gy, mean2, ext, bmin, bmax);
+        if (prm->tile_culling) {
+            const float* con = conic_opacity + 4 * (size_t)i;
+            const float max_power = det_logf(con[3] / prm->alpha_threshold);
+            for (int y = bmin[1]; (y < bmax[1]) && (off < max_off); ++y)
+                for (int x = bmin[0]; (x < bmax[0]) && (off < max_off); ++x)
+                    if (tile_min_power((float)x, (float)y, con, mean2) < max_power) {
+                        keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dkey;
+                        ids[off] = i;
+                        off++;
+                    }
+            for (; off < max_off; ++off) {
+                keys[off] = ((uint64_t)INVALID_IDX << 32) | f2u(3.4028235e+38f);
+                ids[off] = INVALID_IDX;
+            }
+        } else {
+            for (int y = bmin[1]; y < bmax[1]; ++y)
+                for (int x = bmin[0]; x < bmax[0]; ++x) {
+                    keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dkey;
+                    ids[off] = i;
+                    off++;
+                }
+        }
+    }
+}
+
+/* higherMsb — gutRenderer.cu:79-94 (== bit_width for n >= 1) */
+uint32_t oracle_higher_msb(uint32_t n) {
+    uint32_t msb = 16, step = 16;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/* K4: stable LSD radix sort of (key,value) on bits [0,end_bit) — cub::DeviceRadixSort::SortPairs,
+ * gutRenderer.cu:356-365 */
+void oracle_sort_pairs(uint32_t M, int end_bit, const uint64_t* keys_in, const uint32_t* vals_in,
+                       uint64_t* keys_out, uint32_t* vals_out) {
+    if (M == 0) return;
+    uint64_t* ka = (uint64_t*)malloc(sizeof(uint64_t) * M);
+    uint64_t* kb = (uint64_t*)malloc(sizeof(uint64_t) * M);
+    uint32_t* va = (uint32_t*)malloc(sizeof(uint32_t) * M);
+    uint32_t* vb = (uint32_t*)malloc(sizeof(uint32_t) * M);
+    memcpy(ka, keys_in, sizeof(uint64_t) * M);
+    memcpy(va, vals_in, sizeof(uint32_t) * M);
+    for (int bit = 0; bit < end_bit; bit += 8) {
+        const int nb = (end_bit - bit) < 8 ? (end_bit - bit) : 8;
+        const uint64_t mask = ((uint64_t)1 << nb) - 1;
+        size_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        for (uint32_t i = 0; i < M; ++i) hist[((ka[i] >> bit) & mask) + 1]++;
+        for (int d = 0; d < 256; ++d) hist[d + 1] += hist[d];
+        for (uint32_t i = 0; i < M; ++i) {
+            const size_t p = hist[(ka[i] >> bit) & mask]++;
+            kb[p] = ka[i]; vb[p] = va[i];
+        }
+        uint64_t* tk = ka; ka = kb; kb = tk;
+        uint32_t* tv = va; va = vb; vb = tv;
+    }
+    memcpy(keys_out, ka, sizeof(uint64_t) * M);
+    memcpy(vals_out, va, sizeof(uint32_t) * M);
+    free(ka); free(kb); free(va); free(vb);
+}
+
+/* K5: computeSortedTileRangeIndices — gutRenderer.cu:46-76; ranges[2*T] pre-zeroed here */
+void oracle_tile_ranges(uint32_t M, uint32_t T, const uint64_t* sorted_keys, uint32_t* ranges) {
+    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)T);
+    for (uint32_t k = 0; k < M; ++k) {
+        const uint32_t tile = (uint32_t)(sorted_keys[k] >> 32);
+        const int valid = tile != INVALID_IDX;
+        if (k == 0) {
+            if (valid) ranges[2 * tile] = 0;
+        } else {
+            const uint32_t prev = (uint32_t)(sorted_keys[k - 1] >> 32);
+            if (prev != tile) {
+                if (prev != INVALID_IDX) ranges[2 * prev + 1] = k;
+                if (valid) ranges[2 * tile] = k;
+            }
+        }
+        if (valid && (k == M - 1)) ranges[2 * tile + 1] = M;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ray setup — common/rayPayload.cuh:76-108, utils/bounding_box.h:88-134
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float o[3], d[3], tmin, tmax; int alive; } Ray;
+
+static void aabb_intersect(const float o[3], const float d[3], float* tmin_out, float* tmax_out) {
+    const float lo = -1e06f, hi = 1e06f, fmax_ = 3.4028235e+38f;
+    float tmin = (lo - o[0]) / d[0], tmax = (hi - o[0]) / d[0];
+    if (tmin > tmax) { float t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (lo - o[1]) / d[1], tymax = (hi - o[1]) / d[1];
+    if (tymin > tymax) { float t = tymin; tymin = tymax; tymax = t; }
+    if (tmin > tymax || tymin > tmax) { *tmin_out = fmax_; *tmax_out = fmax_; return; }
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (lo - o[2]) / d[2], tzmax = (hi - o[2]) / d[2];
+    if (tzmin > tzmax) { float t = tzmin; tzmin = tzmax; tzmax = t; }
+    if (tmin > tzmax || tzmin > tmax) { *tmin_out = fmax_; *tmax_out = fmax_; return; }
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    *tmin_out = tmin; *tmax_out = tmax;
+}
+
+static Ray make_ray(const PoseSet* ps, const float* ro, const float* rd) {
+    Ray r;
+    for (int k = 0; k < 3; ++k) {
+        r.o[k] = ps->Rinv.c[0][k] * ro[0] + ps->Rinv.c[1][k] * ro[1] + ps->Rinv.c[2][k] * ro[2] + ps->cam[k];
+        r.d[k] = ps->Rinv.c[0][k] * rd[0] + ps->Rinv.c[1][k] * rd[1] + ps->Rinv.c[2][k] * rd[2];
+    }
+    aabb_intersect(r.o, r.d, &r.tmin, &r.tmax);
+    r.tmin = r.tmin > 0.0f ? r.tmin : 0.0f; /* fmaxf(tmin, 0) */
+    r.alive = r.tmax > r.tmin;
+    return r;
+}
+
+/* per-(ray, particle) response — slang/models/gaussianParticles.slang:96-222 */
+typedef struct { float gro[3], grdu[3], grd[3], gposc[3], gposcr[3], rdr[3], d2, resp, alpha; } Hit;
+
+static void eval_hit(const OracleParams* prm, const float* g, const float rows[3][3], const Ray* ray, Hit* h) {
+    const float* mu = g; const float* s = g + 8; const float sigma = g[3];
+    for (int k = 0; k < 3; ++k) h->gposc[k] = ray->o[k] - mu[k];
+    for (int k = 0; k < 3; ++k) {
+        h->gposcr[k] = rows[k][0] * h->gposc[0] + rows[k][1] * h->gposc[1] + rows[k][2] * h->gposc[2];
+        h->rdr[k] = rows[k][0] * ray->d[0] + rows[k][1] * ray->d[1] + rows[k][2] * ray->d[2];
+        h->gro[k] = (1.0f / s[k]) * h->gposcr[k];
+        h->grdu[k] = (1.0f / s[k]) * h->rdr[k];
+    }
+    const float l2 = h->grdu[0] * h->grdu[0] + h->grdu[1] * h->grdu[1] + h->grdu[2] * h->grdu[2];
+    const float il = l2 > 0.0f ? 1.0f / sqrtf(l2) : 1.0f;
+    for (int k = 0; k < 3; ++k) h->grd[k] = h->grdu[k] * il;
+    const float c0 = h->grd[1] * h->gro[2] - h->grd[2] * h->gro[1];
+    const float c1 = h->grd[2] * h->gro[0] - h->grd[0] * h->gro[2];
+    const float c2 = h->grd[0] * h->gro[1] - h->grd[1] * h->gro[0];
+    h->d2 = c0 * c0 + c1 * c1 + c2 * c2;
+    h->resp = expf(-0.5f * h->d2);
+    const float a = h->resp * sigma;
+    h->alpha = a < prm->max_alpha ? a : prm->max_alpha;
+}
+
+/* K6: render — gutRenderer.cuh:83-115, gutKBufferRenderer.cuh:108-170,217-292 (K=0),
+ * rayPayload.cuh:110-129.  Also returns per-tile traversal counts (entries fetched before the
+ * whole tile terminated) for the roofline statistics E_f. */
+void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+                   const float* density12, const float* feat,
+                   const float* ray_ori, const float* ray_dir,
+                   const uint32_t* ranges, const uint32_t* sorted_ids,
+                   float* rgba, float* dist, float* hits, uint64_t* traversed_out) {
+    const PoseSet ps = make_pose_set(cam);
+    const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
+    uint64_t traversed_total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : traversed_total)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+        uint32_t deepest = 0;
+        for (int py = ty * GUT_TILE; py < (ty + 1) * GUT_TILE && py < H; ++py)
+            for (int px = tx * GUT_TILE; px < (tx + 1) * GUT_TILE && px < W; ++px) {
+                const size_t pix = (size_t)py * W + px;
+                Ray ray = make_ray(&ps, ray_ori + 3 * pix, ray_dir + 3 * pix);
+                if (!ray.alive) continue; /* invalid rays keep the caller's initial outputs */
+                float T = 1.0f, rgb[3] = {0, 0, 0}, dsum = 0.0f;
+                uint32_t nh = 0;
+                uint32_t k = beg;
+                for (; k < end && ray.alive; ++k) {
+                    const uint32_t id = sorted_ids[k];
+                    if (id == INVALID_IDX) break;
+                    const float* g = density12 + (size_t)id * 12;
+                    float rows[3][3];
+                    quat_to_rows(g + 4, rows);
+                    Hit h;
+                    eval_hit(prm, g, rows, &ray, &h);
+                    if ((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold)) {
+                        const float* s = g + 8;
+                        const float proj = h.grd[0] * -h.gro[0] + h.grd[1] * -h.gro[1] + h.grd[2] * -h.gro[2];
+                        const float v0 = s[0] * h.grd[0] * proj, v1 = s[1] * h.grd[1] * proj, v2 = s[2] * h.grd[2] * proj;
+                        const float hit_t = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+                        if ((hit_t > ray.tmin) && (hit_t < ray.tmax)) {
+                            const float w = h.alpha * T;
+                            dsum += hit_t * w;
+                            T *= (1.0f - h.alpha);
+                            if (w > 0.0f) {
+                                for (int c = 0; c < 3; ++c) {
+                                    const float f = feat[3 * (size_t)id + c];
+                                    rgb[c] += (f > 0.0f ? f : 0.0f) * w;
+                                }
+                                nh++;
+                            }
+                            if (T < prm->min_transmittance) ray.alive = 0;
+                        }
+                    }
+                }
+                if (k - beg > deepest) deepest = k - beg;
+                rgba[4 * pix] = rgb[0]; rgba[4 * pix + 1] = rgb[1]; rgba[4 * pix + 2] = rgb[2];
+                rgba[4 * pix + 3] = 1.0f - T;
+                dist[pix] = dsum;
+                hits[pix] = (float)nh;
+            }
+        traversed_total += deepest;
+    }
+    if (traversed_out) *traversed_out = traversed_total;
+}
+
+/* matmul_bw_quat — common/mathUtils.cuh:468-533 */
+static void matmul_bw_quat(const float p[3], const float g[3], const float q[4], float out[4]) {
+    float dm[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dm[i][j] = g[i] * p[j];
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    float dr = 0, dx = 0, dy = 0, dz = 0;
+    dy += -4 * y * dm[0][0]; dz += -4 * z * dm[0][0];
+    dr += 2 * z * dm[0][1]; dx += 2 * y * dm[0][1]; dy += 2 * x * dm[0][1]; dz += 2 * r * dm[0][1];
+    dr += -2 * y * dm[0][2]; dx += 2 * z * dm[0][2]; dy += -2 * r * dm[0][2]; dz += 2 * x * dm[0][2];
+    dr += -2 * z * dm[1][0]; dx += 2 * y * dm[1][0]; dy += 2 * x * dm[1][0]; dz += -2 * r * dm[1][0];
+    dx += -4 * x * dm[1][1]; dz += -4 * z * dm[1][1];
+    dr += 2 * x * dm[1][2]; dx += 2 * r * dm[1][2]; dy += 2 * z * dm[1][2]; dz += 2 * y * dm[1][2];
+    dr += 2 * y * dm[2][0]; dx += 2 * z * dm[2][0]; dy += 2 * r * dm[2][0]; dz += 2 * x * dm[2][0];
+    dr += -2 * x * dm[2][1]; dx += -2 * r * dm[2][1]; dy += 2 * z * dm[2][1]; dz += 2 * y * dm[2][1];
+    dx += -4 * x * dm[2][2]; dy += -4 * y * dm[2][2];
+    out[0] = dr; out[1] = dx; out[2] = dy; out[3] = dz;
+}
+
+/* K7: renderBackward — gutKBufferRenderer.cuh:294-386, models/gaussianParticles.cuh:480-738,
+ * rayPayloadBackward.cuh:30-58.  Per-pair math in fp32 exactly as the reference; the cross-pixel
+ * sums (float atomics in the reference, order undefined) are taken in double here.
+ * Quirk 1: integratedDepth == 0 so residualHitT == 0.
+ * density_grad [N,12] (pos3, density, quat4 wxyz, scale3, pad) and feat_grad [N,3], both doubles. */
+void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+                       const float* density12, const float* feat,
+                       const float* ray_ori, const float* ray_dir,
+                       const uint32_t* ranges, const uint32_t* sorted_ids,
+                       const float* rgba, const float* rgba_grad, const float* dist, const float* dist_grad,
+                       double* density_grad, double* feat_grad, uint64_t* traversed_out) {
+    const PoseSet ps = make_pose_set(cam);
+    const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
+    uint64_t traversed_total = 0;
+    (void)dist;
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+        uint32_t deepest = 0;
+        for (int py = ty * GUT_TILE; py < (ty + 1) * GUT_TILE && py < H; ++py)
+            for (int px = tx * GUT_TILE; px < (tx + 1) * GUT_TILE && px < W; ++px) {
+                const size_t pix = (size_t)py * W + px;
+                Ray ray = make_ray(&ps, ray_ori + 3 * pix, ray_dir + 3 * pix);
+                if (!ray.alive) continue;
+                const float T_final = 1.0f - rgba[4 * pix + 3];
+                const float T_grad = -1.0f * rgba_grad[4 * pix + 3];
+                const float rgb_final[3] = {rgba[4 * pix], rgba[4 * pix + 1], rgba[4 * pix + 2]};
+                const float rgb_g[3] = {rgba_grad[4 * pix], rgba_grad[4 * pix + 1], rgba_grad[4 * pix + 2]};
+                const float depth_g = dist_grad[pix];
+                float T = 1.0f, rgb_run[3] = {0, 0, 0};
+                uint32_t k = beg;
+                for (; k < end && ray.alive; ++k) {
+                    const uint32_t id = sorted_ids[k];
+                    if (id == INVALID_IDX) break;
+                    const float* g = density12 + (size_t)id * 12;
+                    const float* q = g + 4; const float* s = g + 8; const float sigma = g[3];
+                    float rows[3][3];
+                    quat_to_rows(q, rows);
+                    Hit h;
+                    eval_hit(prm, g, rows, &ray, &h);
+                    if (!((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold))) continue;
+                    /* NB: no tmin/tmax test in the backward (gaussianParticles.cuh:530) */
+                    const float proj = h.grd[0] * -h.gro[0] + h.grd[1] * -h.gro[1] + h.grd[2] * -h.gro[2];
+                    const float grdd[3] = {h.grd[0] * proj, h.grd[1] * proj, h.grd[2] * proj};
+                    const float grds[3] = {s[0] * grdd[0], s[1] * grdd[1], s[2] * grdd[2]};
+                    const float gsq = grds[0] * grds[0] + grds[1] * grds[1] + grds[2] * grds[2];
+                    const float gdist = sqrtf(gsq);
+                    const float w = h.alpha * T;
+                    const float Tn = (1.0f - h.alpha) * T;
+                    const float res_hit = 0.0f; /* quirk 1 */
+                    const float ga_hit = (gdist - res_hit) * T * depth_g;
+                    float g_grds[3] = {0, 0, 0};
+                    if (gsq > 0.0f) for (int c = 0; c < 3; ++c) g_grds[c] = ((2.0f * grds[c] * w) / (2.0f * gdist)) * depth_g;
+                    const float gs_hit[3] = {grdd[0] * g_grds[0], grdd[1] * g_grds[1], grdd[2] * g_grds[2]};
+                    const float gx0 = h.grd[0] * h.gro[0], gy0 = h.grd[1] * h.gro[1], gz0 = h.grd[2] * h.gro[2];
+                    const float ggrd_hit[3] = {-s[0] * (2 * gx0 + gy0 + gz0) * g_grds[0],
+                                               -s[1] * (gx0 + 2 * gy0 + gz0) * g_grds[1],
+                                               -s[2] * (gx0 + gy0 + 2 * gz0) * g_grds[2]};
+                    const float ggro_hit[3] = {-s[0] * h.grd[0] * h.grd[0] * g_grds[0],
+                                               -s[1] * h.grd[1] * h.grd[1] * g_grds[1],
+                                               -s[2] * h.grd[2] * h.grd[2] * g_grds[2]};
+                    const float res_T = h.alpha < 0.999999f ? T_final / (1.0f - h.alpha) : T;
+                    const float ga_dns = res_T * -T_grad;
+                    float f[3], res_rad[3];
+                    for (int c = 0; c < 3; ++c) {
+                        const float fv = feat[3 * (size_t)id + c];
+                        f[c] = fv > 0.0f ? fv : 0.0f;
+                        feat_grad[3 * (size_t)id + c] += (double)(rgb_g[c] * w);
+                        rgb_run[c] += w * f[c];
+                        const float rr = (Tn <= prm->min_transmittance) ? 0.0f : (rgb_final[c] - rgb_run[c]) / Tn;
+                        res_rad[c] = rr > 0.0f ? rr : 0.0f;
+                    }
+                    const float G = ga_hit + ga_dns + T * (f[0] - res_rad[0]) * rgb_g[0] + T * (f[1] - res_rad[1]) * rgb_g[1] +
+                                    T * (f[2] - res_rad[2]) * rgb_g[2];
+                    const float d_sigma = h.resp * G;
+                    const float g_resp = sigma * G;
+                    const float g_d2 = -0.5f * h.resp * g_resp;
+                    const float cr[3] = {h.grd[1] * h.gro[2] - h.grd[2] * h.gro[1], h.grd[2] * h.gro[0] - h.grd[0] * h.gro[2],
+                                         h.grd[0] * h.gro[1] - h.grd[1] * h.gro[0]};
+                    const float gc[3] = {2 * cr[0] * g_d2, 2 * cr[1] * g_d2, 2 * cr[2] * g_d2};
+                    const float g_grd[3] = {gc[2] * h.gro[1] - gc[1] * h.gro[2], gc[0] * h.gro[2] - gc[2] * h.gro[0],
+                                            gc[1] * h.gro[0] - gc[0] * h.gro[1]};
+                    const float g_gro[3] = {gc[1] * h.grd[2] - gc[2] * h.grd[1], gc[2] * h.grd[0] - gc[0] * h.grd[2],
+                                            gc[0] * h.grd[1] - gc[1] * h.grd[0]};
+                    float gs_gro[3], g_gposcr[3];
+                    for (int c = 0; c < 3; ++c) {
+                        gs_gro[c] = (-h.gposcr[c] / (s[c] * s[c])) * (g_gro[c] + ggro_hit[c]);
+                        g_gposcr[c] = (1.0f / s[c]) * (g_gro[c] + ggro_hit[c]);
+                    }
+                    float g_gposc[3];
+                    for (int c = 0; c < 3; ++c) g_gposc[c] = g_gposcr[0] * rows[0][c] + g_gposcr[1] * rows[1][c] + g_gposcr[2] * rows[2][c];
+                    float q_a[4];
+                    matmul_bw_quat(h.gposc, g_gposcr, q, q_a);
+                    /* safe_normalize_bw(grdu, g_grd + ggrd_hit), mathUtils.cuh:420-430 */
+                    const float gin[3] = {g_grd[0] + ggrd_hit[0], g_grd[1] + ggrd_hit[1], g_grd[2] + ggrd_hit[2]};
+                    float g_grdu[3] = {0, 0, 0};
+                    {
+                        const float* v = h.grdu;
+                        const float l = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+                        if (l > 0.0f) {
+                            const float il = 1.0f / sqrtf(l);
+                            const float il3 = il * il * il;
+                            g_grdu[0] = il * gin[0] - il3 * (gin[0] * (v[0] * v[0]) + gin[1] * (v[1] * v[0]) + gin[2] * (v[2] * v[0]));
+                            g_grdu[1] = il * gin[1] - il3 * (gin[0] * (v[0] * v[1]) + gin[1] * (v[1] * v[1]) + gin[2] * (v[2] * v[1]));
+                            g_grdu[2] = il * gin[2] - il3 * (gin[0] * (v[0] * v[2]) + gin[1] * (v[1] * v[2]) + gin[2] * (v[2] * v[2]));
+                        }
+                    }
+                    float g_rdr[3], d_scale[3];
+                    for (int c = 0; c < 3; ++c) {
+                        d_scale[c] = gs_hit[c] + gs_gro[c] + (-h.rdr[c] / (s[c] * s[c])) * g_grdu[c];
+                        g_rdr[c] = (1.0f / s[c]) * g_grdu[c];
+                    }
+                    float q_b[4];
+                    matmul_bw_quat(ray.d, g_rdr, q, q_b);
+                    double* dg = density_grad + 12 * (size_t)id;
+                    dg[0] += (double)(-g_gposc[0]); dg[1] += (double)(-g_gposc[1]); dg[2] += (double)(-g_gposc[2]);
+                    dg[3] += (double)d_sigma;
+                    for (int c = 0; c < 4; ++c) dg[4 + c] += (double)(q_a[c] + q_b[c]);
+                    for (int c = 0; c < 3; ++c) dg[8 + c] += (double)d_scale[c];
+                    T = Tn;
+                    if (T < prm->min_transmittance) ray.alive = 0;
+                }
+                if (k - beg > deepest) deepest = k - beg;
+            }
+        traversed_total += deepest;
+    }
+    if (traversed_out) *traversed_out = traversed_total;
+}
+
+/* K8: projectBackward — gutProjector.cuh:390-430, gaussianParticles.cuh:120-187.
+ * sph_grad [N,48] doubles, overwritten (zero for Gaussians without tiles / above the active degree). */
+void oracle_project_bwd(const OracleCamera* cam, uint32_t N, int sh_degree,
+                        const float* density12, const uint32_t* tiles_count,
+                        const float* feat, const double* feat_grad, double* sph_grad) {
+    const PoseSet ps = make_pose_set(cam);
+    memset(sph_grad, 0, sizeof(double) * 48 * (size_t)N);
+    for (uint32_t i = 0; i < N; ++i) {
+        if (tiles_count[i] == 0) continue;
+        const float* g = density12 + (size_t)i * 12;
+        const float sr[3] = {g[0] - ps.cam[0], g[1] - ps.cam[1], g[2] - ps.cam[2]};
+        const float l = sqrtf(sr[0] * sr[0] + sr[1] * sr[1] + sr[2] * sr[2]);
+        const float dir[3] = {sr[0] / l, sr[1] / l, sr[2] / l};
+        float Y[16];
+        sh_basis(sh_degree, dir, Y);
+        const int ncoef = (sh_degree + 1) * (sh_degree + 1);
+        for (int ch = 0; ch < 3; ++ch) {
+            const double gmask = feat[3 * (size_t)i + ch] > 0.0f ? feat_grad[3 * (size_t)i + ch] : 0.0;
+            for (int k = 0; k < ncoef; ++k) sph_grad[48 * (size_t)i + 3 * k + ch] = (double)Y[k] * gmask;
+        }
+    }
+}
+
+/* exported scalar probes for known-answer tests */
+float oracle_det_logf(float x) { return det_logf(x); }
+float oracle_det_atan2f(float y, float x) { return det_atan2f_pos(y, x); }
+float oracle_tile_min_power(float tx, float ty, const float* conic4, const float* mean2) { return tile_min_power(tx, ty, conic4, mean2); }
