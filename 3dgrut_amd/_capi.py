@@ -1,0 +1,96 @@
+"""ctypes binding of libgut_hip.so (C ABI in include/gut_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to load this module
+raises, and every Tracer call fails loudly.  (The CPU oracle under oracle/ is test infrastructure and
+is never imported from here.)
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgut_hip.so")
+
+GUT_ABI_VERSION = 1
+GUT_NUM_KERNEL_TIMERS = 8
+KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd")
+
+SHUTTER_GLOBAL = 4
+CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
+
+BUF = dict(tiles_count=0, tiles_offset=1, proj_pos=2, conic_opacity=3, extent=4, depth=5, feat=6,
+           unsorted_keys=7, unsorted_ids=8, sorted_keys=9, sorted_ids=10, tile_ranges=11, grad_scratch=12)
+
+
+class GutCamera(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("shutter", C.c_int32),
+        ("principal_point", C.c_float * 2), ("focal_length", C.c_float * 2),
+        ("radial_coeffs", C.c_float * 6), ("tangential_coeffs", C.c_float * 2), ("thin_prism_coeffs", C.c_float * 4),
+        ("max_angle", C.c_float), ("pose_start", C.c_float * 7), ("pose_end", C.c_float * 7),
+        ("timestamp_start_us", C.c_int64), ("timestamp_end_us", C.c_int64),
+    ]
+
+
+class GutConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("enable_kernel_timings", C.c_int32), ("particle_radiance_sph_degree", C.c_int32),
+        ("particle_kernel_degree", C.c_int32), ("k_buffer_size", C.c_int32), ("global_z_order", C.c_int32),
+        ("n_rolling_shutter_iterations", C.c_int32), ("ut_require_all_sigma_points", C.c_int32),
+        ("rect_bounding", C.c_int32), ("tight_opacity_bounding", C.c_int32), ("tile_based_culling", C.c_int32),
+        ("enable_hitcounts", C.c_int32),
+        ("particle_kernel_min_response", C.c_float), ("particle_kernel_min_alpha", C.c_float),
+        ("particle_kernel_max_alpha", C.c_float), ("min_transmittance", C.c_float),
+        ("ut_alpha", C.c_float), ("ut_beta", C.c_float), ("ut_kappa", C.c_float), ("ut_in_image_margin_factor", C.c_float),
+    ]
+
+
+class GutStats(C.Structure):
+    _fields_ = [
+        ("num_particles", C.c_uint64), ("num_visible", C.c_uint64), ("num_intersections", C.c_uint64),
+        ("num_tiles", C.c_uint64), ("num_pixels", C.c_uint64), ("traversed_fwd", C.c_uint64),
+        ("traversed_bwd", C.c_uint64), ("sort_end_bit", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
+           "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_last_error", "gut_abi_version")
+
+_lib = None
+
+
+def load():
+    """Load libgut_hip.so (raises RuntimeError with build instructions if it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the 3DGUT HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). There is no CPU fallback in the product path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, i32, f_p = C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p
+    lib.gut_last_error.restype = C.c_char_p
+    lib.gut_abi_version.restype = C.c_int
+    lib.gut_default_config.argtypes = [C.POINTER(GutConfig)]
+    lib.gut_default_config.restype = None
+    lib.gut_create.argtypes = [C.POINTER(GutConfig), C.c_int, C.POINTER(vp)]
+    lib.gut_destroy.argtypes = [vp]
+    lib.gut_destroy.restype = None
+    lib.gut_trace.argtypes = [vp, vp, u32, i32, u32, f_p, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera), f_p, f_p, f_p, f_p]
+    lib.gut_trace_bwd.argtypes = [vp, vp, u32, i32, u32, f_p, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera),
+                                  f_p, f_p, f_p, f_p, f_p, f_p]
+    lib.gut_collect_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.gut_get_stats.argtypes = [vp, C.POINTER(GutStats)]
+    lib.gut_debug_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.gut_debug_copy.argtypes = [vp, i32, vp, C.c_size_t]
+    lib.gut_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
+    if lib.gut_abi_version() != GUT_ABI_VERSION:
+        raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gut_last_error()
+        raise RuntimeError(f"[3dgut] {what}: {msg.decode() if msg else 'unknown error'}")

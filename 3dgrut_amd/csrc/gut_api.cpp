@@ -1,0 +1,571 @@
+// gut_api.cpp — host side of libgut_hip.so: handle, grow-only scratch, launch orchestration and the C ABI
+// declared in include/gut_hip.h.  Replaces, for the 3DGUT path, the reference's SplatRaster
+// (src/splatRaster.cpp:153-364) and GUTRenderer (src/gutRenderer.cu:99-497).
+//
+// Compiled with -ffp-contract=off: the pose matrices built here feed the bit-exact projection kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "gut_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    // grow-only (gutRenderer.cu:136-231 resizes the same way); returns hipSuccess or the allocation error
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (p) {
+            hipError_t e = hipFree(p);  // synchronises the device: safe w.r.t. in-flight users
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool armed = false;
+};
+
+// ---- pose math (fp32, GLM-equivalent definitions of the tiny-cuda-nn calls in sensors/sensors.h:44-73) ----
+void quat_to_rot(float w, float x, float y, float z, float r[3][3] /* row-major */) {
+    const float qxx = x * x, qyy = y * y, qzz = z * z;
+    const float qxz = x * z, qxy = x * y, qyz = y * z;
+    const float qwx = w * x, qwy = w * y, qwz = w * z;
+    // column-major definition m[col][row], written out row-major here
+    r[0][0] = 1.0f - 2.0f * (qyy + qzz); r[1][0] = 2.0f * (qxy + qwz); r[2][0] = 2.0f * (qxz - qwy);
+    r[0][1] = 2.0f * (qxy - qwz); r[1][1] = 1.0f - 2.0f * (qxx + qzz); r[2][1] = 2.0f * (qyz + qwx);
+    r[0][2] = 2.0f * (qxz + qwy); r[1][2] = 2.0f * (qyz - qwx); r[2][2] = 1.0f - 2.0f * (qxx + qyy);
+}
+
+void interpolate_pose(const float* a, const float* b, float t, float* out) {
+    float qa[4] = {a[6], a[3], a[4], a[5]};
+    float qb[4] = {b[6], b[3], b[4], b[5]};
+    float cos_t = qa[0] * qb[0] + qa[1] * qb[1] + qa[2] * qb[2] + qa[3] * qb[3];
+    if (cos_t < 0.0f) {
+        for (int i = 0; i < 4; ++i) qb[i] = -qb[i];
+        cos_t = -cos_t;
+    }
+    float q[4];
+    if (cos_t > 1.0f - 1.1920929e-07f) {
+        for (int i = 0; i < 4; ++i) q[i] = qa[i] * (1.0f - t) + qb[i] * t;
+    } else {
+        const float ang = acosf(cos_t);
+        const float s0 = sinf((1.0f - t) * ang), s1 = sinf(t * ang), sd = sinf(ang);
+        for (int i = 0; i < 4; ++i) q[i] = (s0 * qa[i] + s1 * qb[i]) / sd;
+    }
+    for (int i = 0; i < 3; ++i) out[i] = a[i] * (1.0f - t) + b[i] * t;
+    out[3] = q[1]; out[4] = q[2]; out[5] = q[3]; out[6] = q[0];
+}
+
+uint32_t bit_width_u32(uint32_t n) {  // == higherMsb of gutRenderer.cu:79-94 for n >= 1
+    uint32_t w = 0;
+    while (n) { ++w; n >>= 1; }
+    return w;
+}
+
+}  // namespace
+
+struct gut_context {
+    int device = 0;
+    GutConfig cfg{};
+    gut::RenderConsts consts{};
+    std::mutex mu;
+
+    // per-N scratch
+    DevBuf tiles_count, tiles_offset, proj_pos, conic_opacity, extent, depth, feat, grad16, scan_temp;
+    // per-M scratch
+    DevBuf keys_unsorted, keys_sorted, ids_unsorted, ids_sorted, sort_temp;
+    // per-T
+    DevBuf ranges;
+    DevBuf counters;
+    uint32_t* host_count = nullptr;  // pinned
+
+    // cached forward context (gutRenderer.cu:252-254, 413)
+    bool have_forward = false;
+    hipStream_t fwd_stream = nullptr;
+    uint32_t n = 0, m = 0;
+    int width = 0, height = 0, tiles = 0, sh_degree = 0, end_bit = 0;
+    gut::ViewParams view{};
+    bool have_backward = false;
+
+    // timers
+    std::deque<EventPair> fwd_timers, bwd_timers;
+    float last_fwd_ms = -1.f, last_bwd_ms = -1.f;
+    hipEvent_t kev[16] = {};  // per-kernel boundaries of the last call
+    bool kev_fwd_valid = false, kev_bwd_valid = false;
+};
+
+namespace {
+
+int build_view(const GutCamera* cam, int W, int H, gut::ViewParams* v) {
+    if (cam->model != GUT_CAMERA_OPENCV_PINHOLE && cam->model != GUT_CAMERA_OPENCV_FISHEYE)
+        return fail("unsupported camera model %d (only OpenCV pinhole / fisheye exist in the reference)", cam->model);
+    if (cam->shutter != GUT_SHUTTER_GLOBAL)
+        return fail("rolling-shutter type %d is not implemented in this build (global shutter only)", cam->shutter);
+    memset(v, 0, sizeof(*v));
+    const float* s = cam->pose_start;
+    quat_to_rot(s[6], s[3], s[4], s[5], v->w2s_start.r);
+    for (int i = 0; i < 3; ++i) v->w2s_start.t[i] = s[i];
+    float mid[7];
+    interpolate_pose(cam->pose_start, cam->pose_end, 0.5f, mid);
+    quat_to_rot(mid[6], mid[3], mid[4], mid[5], v->w2s_mid.r);
+    for (int i = 0; i < 3; ++i) v->w2s_mid.t[i] = mid[i];
+    // sensor->world = (R^T, -R^T t).  The reference round-trips R^T through a quaternion
+    // (sensors.h:44-53); skipping that removes rounding noise and changes no integer buffer.
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) v->s2w.r[r][c] = v->w2s_mid.r[c][r];
+    for (int r = 0; r < 3; ++r)
+        v->s2w.t[r] = -1.0f * (v->s2w.r[r][0] * mid[0] + v->s2w.r[r][1] * mid[1] + v->s2w.r[r][2] * mid[2]);
+    v->model = cam->model;
+    v->width = W;
+    v->height = H;
+    v->grid_x = (W + gut::kTile - 1) / gut::kTile;
+    v->grid_y = (H + gut::kTile - 1) / gut::kTile;
+    for (int i = 0; i < 2; ++i) {
+        v->principal_point[i] = cam->principal_point[i];
+        v->focal_length[i] = cam->focal_length[i];
+        v->tangential[i] = cam->tangential_coeffs[i];
+    }
+    for (int i = 0; i < 6; ++i) v->radial[i] = cam->radial_coeffs[i];
+    for (int i = 0; i < 4; ++i) v->thin_prism[i] = cam->thin_prism_coeffs[i];
+    v->max_angle = cam->max_angle;
+    return 0;
+}
+
+void build_consts(const GutConfig& cfg, gut::RenderConsts* c) {
+    c->alpha_threshold = cfg.particle_kernel_min_alpha;
+    c->max_alpha = cfg.particle_kernel_max_alpha;
+    c->min_response = cfg.particle_kernel_min_response;
+    c->min_transmittance = cfg.min_transmittance;
+    c->min_sensor_z = 0.2f;   // threedgut.cuh:49
+    c->cov_dilation = 0.3f;   // threedgut.cuh:50
+    const float D = 3.0f;
+    const float lambda = cfg.ut_alpha * cfg.ut_alpha * (D + cfg.ut_kappa) - D;
+    c->ut_delta = sqrtf(cfg.ut_alpha * cfg.ut_alpha * (D + cfg.ut_kappa));
+    c->ut_w0_mean = lambda / (D + lambda);
+    c->ut_wi = 1.0f / (2.0f * (D + lambda));
+    c->ut_w0_cov = lambda / (D + lambda) + (1.0f - cfg.ut_alpha * cfg.ut_alpha + cfg.ut_beta);
+    c->ut_margin = cfg.ut_in_image_margin_factor;
+    c->rect_bounding = cfg.rect_bounding;
+    c->tight_opacity_bounding = cfg.tight_opacity_bounding;
+    c->tile_culling = cfg.tile_based_culling;
+    c->global_z_order = cfg.global_z_order;
+    c->max_d2 = -2.0f * logf(cfg.particle_kernel_min_response);
+}
+
+EventPair* arm_timer(std::deque<EventPair>& q, hipStream_t s) {
+    if (q.size() >= 256) {  // keep only the most recent (splatRaster.cpp:212-215)
+        EventPair old = q.front();
+        q.pop_front();
+        if (old.a) (void)hipEventDestroy(old.a);
+        if (old.b) (void)hipEventDestroy(old.b);
+    }
+    EventPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+    (void)hipEventRecord(p.a, s);
+    q.push_back(p);
+    return &q.back();
+}
+
+float drain_timers(std::deque<EventPair>& q) {
+    if (q.empty()) return -1.f;
+    float sum = 0.f;
+    int cnt = 0;
+    for (auto& p : q) {
+        if (p.armed && hipEventSynchronize(p.b) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                sum += ms;
+                cnt++;
+            }
+        }
+        if (p.a) (void)hipEventDestroy(p.a);
+        if (p.b) (void)hipEventDestroy(p.b);
+    }
+    q.clear();
+    return cnt ? sum / (float)cnt : -1.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gut_last_error(void) { return g_last_error.c_str(); }
+int gut_abi_version(void) { return GUT_ABI_VERSION; }
+
+void gut_default_config(GutConfig* cfg) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = GUT_ABI_VERSION;
+    cfg->enable_kernel_timings = 0;
+    cfg->particle_radiance_sph_degree = 3;
+    cfg->particle_kernel_degree = 2;
+    cfg->k_buffer_size = 0;
+    cfg->global_z_order = 1;
+    cfg->n_rolling_shutter_iterations = 5;
+    cfg->ut_require_all_sigma_points = 0;
+    cfg->rect_bounding = 1;
+    cfg->tight_opacity_bounding = 1;
+    cfg->tile_based_culling = 1;
+    cfg->enable_hitcounts = 1;
+    cfg->particle_kernel_min_response = 0.0113f;
+    cfg->particle_kernel_min_alpha = 1.0f / 255.0f;
+    cfg->particle_kernel_max_alpha = 0.99f;
+    cfg->min_transmittance = 0.0001f;
+    cfg->ut_alpha = 1.0f;
+    cfg->ut_beta = 2.0f;
+    cfg->ut_kappa = 0.0f;
+    cfg->ut_in_image_margin_factor = 0.1f;
+}
+
+int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
+    if (!cfg || !out) return fail("gut_create: null argument");
+    if (cfg->abi_version != GUT_ABI_VERSION) return fail("gut_create: ABI version %d, library is %d", cfg->abi_version, GUT_ABI_VERSION);
+    // the reference compiles one kernel variant per render config (setup_3dgut.py:47-70); this library ships
+    // the default 3dgut variant and says so instead of silently rendering something else
+    if (cfg->particle_kernel_degree != 2) return fail("particle_kernel_degree=%d: only the quadratic (2) kernel of render/3dgut.yaml is built", cfg->particle_kernel_degree);
+    if (cfg->k_buffer_size != 0) return fail("k_buffer_size=%d: only the unsorted (0) variant is built", cfg->k_buffer_size);
+    if (cfg->particle_radiance_sph_degree != 3) return fail("particle_radiance_sph_degree=%d: only degree 3 (16 coefficients) is built", cfg->particle_radiance_sph_degree);
+    if (cfg->ut_require_all_sigma_points != 0) return fail("ut_require_all_sigma_points must be false (static_assert in threedgut.cuh:73)");
+    if (!cfg->enable_hitcounts) return fail("enable_hitcounts=false is not built");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_index < 0 || device_index >= ndev) return fail("gut_create: device %d out of range (%d devices)", device_index, ndev);
+    HIP_TRY(hipSetDevice(device_index));
+    gut_context* h = new (std::nothrow) gut_context();
+    if (!h) return fail("gut_create: out of host memory");
+    h->device = device_index;
+    h->cfg = *cfg;
+    build_consts(*cfg, &h->consts);
+    hipError_t e = hipHostMalloc((void**)&h->host_count, 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = h->counters.ensure(sizeof(gut::Counters));
+    if (e != hipSuccess) {
+        delete h;
+        return fail("gut_create: allocation failed: %s", hipGetErrorString(e));
+    }
+    for (auto& ev : h->kev)
+        if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+    *out = h;
+    return 0;
+}
+
+void gut_destroy(gut_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
+                      &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
+                      &h->sort_temp, &h->ranges, &h->counters};
+    for (DevBuf* b : bufs) b->release();
+    if (h->host_count) (void)hipHostFree(h->host_count);
+    (void)drain_timers(h->fwd_timers);
+    (void)drain_timers(h->bwd_timers);
+    for (auto& ev : h->kev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete h;
+}
+
+int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+              const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+              const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+              float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+              float* d_particle_visibility) {
+    (void)frame_number;
+    if (!h) return fail("gut_trace: null handle");
+    if (!camera || !d_ray_origin || !d_ray_direction || !d_ray_radiance_density || !d_ray_hit_distance || !d_ray_hit_count)
+        return fail("gut_trace: null pointer argument");
+    if (width <= 0 || height <= 0) return fail("gut_trace: bad resolution %dx%d", width, height);
+    if (num_active_features < 0 || num_active_features > 3) return fail("gut_trace: SH degree %d outside 0..3", num_active_features);
+    if (num_particles && (!d_particle_density || !d_particle_radiance || !d_particle_visibility))
+        return fail("gut_trace: null particle buffers with %u particles", num_particles);
+    std::lock_guard<std::mutex> lock(h->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipSetDevice(h->device));
+    gut::ViewParams v;
+    if (build_view(camera, width, height, &v)) return 1;
+    const uint32_t n = num_particles;
+    const int tiles = v.grid_x * v.grid_y;
+    if ((uint64_t)tiles >= 0xFFFFFFFFull) return fail("gut_trace: too many tiles");
+    h->have_forward = false;
+    h->have_backward = false;
+
+    HIP_TRY(h->tiles_count.ensure(sizeof(uint32_t) * (size_t)n));
+    HIP_TRY(h->tiles_offset.ensure(sizeof(uint32_t) * (size_t)n));
+    HIP_TRY(h->proj_pos.ensure(sizeof(float) * 2 * (size_t)n));
+    HIP_TRY(h->conic_opacity.ensure(sizeof(float) * 4 * (size_t)n));
+    HIP_TRY(h->extent.ensure(sizeof(float) * 2 * (size_t)n));
+    HIP_TRY(h->depth.ensure(sizeof(float) * (size_t)n));
+    HIP_TRY(h->feat.ensure(sizeof(float) * 3 * (size_t)n));
+    HIP_TRY(h->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)tiles));
+    if (n) HIP_TRY(h->scan_temp.ensure(gut::scan_temp_bytes(n)));
+
+    const bool timing = h->cfg.enable_kernel_timings != 0;
+    EventPair* total = timing ? arm_timer(h->fwd_timers, s) : nullptr;
+    h->kev_fwd_valid = false;
+    auto mark = [&](int i) {
+        if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
+    };
+
+    HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(gut::Counters), s));
+    mark(0);
+    gut::launch_project(s, v, h->consts, n, num_active_features, d_particle_density, d_particle_radiance,
+                        h->tiles_count.as<uint32_t>(), h->proj_pos.as<float>(), h->conic_opacity.as<float>(),
+                        h->extent.as<float>(), h->depth.as<float>(), h->feat.as<float>(), d_particle_visibility,
+                        h->counters.as<gut::Counters>());
+    mark(1);
+    uint32_t m = 0;
+    if (n) {
+        HIP_TRY(gut::run_scan(s, h->scan_temp.p, h->scan_temp.cap, h->tiles_count.as<uint32_t>(), h->tiles_offset.as<uint32_t>(), n));
+        // intersection count readback: the one host sync of the path (gutRenderer.cu:313-321)
+        HIP_TRY(hipMemcpyAsync(h->host_count, h->tiles_offset.as<uint32_t>() + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        m = *h->host_count;
+    }
+    mark(2);
+    const int end_bit = 32 + (int)bit_width_u32((uint32_t)tiles);
+    HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
+    if (m) {
+        HIP_TRY(h->keys_unsorted.ensure(sizeof(uint64_t) * (size_t)m));
+        HIP_TRY(h->keys_sorted.ensure(sizeof(uint64_t) * (size_t)m));
+        HIP_TRY(h->ids_unsorted.ensure(sizeof(uint32_t) * (size_t)m));
+        HIP_TRY(h->ids_sorted.ensure(sizeof(uint32_t) * (size_t)m));
+        HIP_TRY(h->sort_temp.ensure(gut::sort_temp_bytes(m, end_bit)));
+        gut::launch_expand(s, v, h->consts, n, h->tiles_offset.as<uint32_t>(), h->proj_pos.as<float>(),
+                           h->conic_opacity.as<float>(), h->extent.as<float>(), h->depth.as<float>(),
+                           h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>());
+        mark(3);
+        HIP_TRY(gut::run_sort(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(), h->keys_sorted.as<uint64_t>(),
+                              h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, end_bit));
+        mark(4);
+        gut::launch_tile_ranges(s, m, h->keys_sorted.as<uint64_t>(), h->ranges.as<uint32_t>());
+    } else {
+        mark(3);
+        mark(4);
+    }
+    mark(5);
+    // with zero intersections the reference returns its freshly initialised outputs (gutRenderer.cu:323-325);
+    // running the compositor over empty ranges writes exactly those values
+    gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
+                       h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_ray_radiance_density, d_ray_hit_distance,
+                       d_ray_hit_count, h->counters.as<gut::Counters>());
+    mark(6);
+    HIP_TRY(hipGetLastError());
+    if (total) {
+        (void)hipEventRecord(total->b, s);
+        total->armed = true;
+    }
+    h->kev_fwd_valid = timing;
+    h->have_forward = true;
+    h->fwd_stream = s;
+    h->n = n;
+    h->m = m;
+    h->width = width;
+    h->height = height;
+    h->tiles = tiles;
+    h->sh_degree = num_active_features;
+    h->end_bit = end_bit;
+    h->view = v;
+    return 0;
+}
+
+int gut_trace_bwd(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                  const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+                  const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                  const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                  const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_particle_density_grad,
+                  float* d_particle_radiance_grad) {
+    (void)frame_number;
+    (void)d_particle_radiance;
+    (void)d_ray_hit_distance;
+    if (!h) return fail("gut_trace_bwd: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    // same contract as the reference: backward needs the forward's cached context on the same stream
+    // (gutRenderer.cu:413-417)
+    if (!h->have_forward || h->fwd_stream != s)
+        return fail("gut_trace_bwd: no forward context on this stream (call gut_trace first, same stream)");
+    if (num_particles != h->n || width != h->width || height != h->height || num_active_features != h->sh_degree)
+        return fail("gut_trace_bwd: arguments differ from the cached forward (N %u vs %u, %dx%d vs %dx%d)", num_particles, h->n,
+                    width, height, h->width, h->height);
+    if (!camera || !d_ray_origin || !d_ray_direction || !d_ray_radiance_density || !d_ray_radiance_density_grad ||
+        !d_ray_hit_distance_grad)
+        return fail("gut_trace_bwd: null pointer argument");
+    if (num_particles && (!d_particle_density || !d_particle_density_grad || !d_particle_radiance_grad))
+        return fail("gut_trace_bwd: null particle buffers");
+    HIP_TRY(hipSetDevice(h->device));
+    gut::ViewParams v;
+    if (build_view(camera, width, height, &v)) return 1;
+    if (memcmp(&v, &h->view, sizeof(v)) != 0) return fail("gut_trace_bwd: camera differs from the cached forward");
+    const uint32_t n = h->n;
+    if (n == 0) return 0;
+    HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)n));
+
+    const bool timing = h->cfg.enable_kernel_timings != 0;
+    EventPair* total = timing ? arm_timer(h->bwd_timers, s) : nullptr;
+    h->kev_bwd_valid = false;
+    auto mark = [&](int i) {
+        if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
+    };
+    mark(8);
+    HIP_TRY(hipMemsetAsync(h->grad16.p, 0, sizeof(float) * 16 * (size_t)n, s));
+    mark(9);
+    if (h->m)
+        gut::launch_render_bwd(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
+                               h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_ray_radiance_density,
+                               d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
+                               h->counters.as<gut::Counters>());
+    mark(10);
+    gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
+                            h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad);
+    mark(11);
+    HIP_TRY(hipGetLastError());
+    if (total) {
+        (void)hipEventRecord(total->b, s);
+        total->armed = true;
+    }
+    h->kev_bwd_valid = timing;
+    h->have_backward = true;
+    return 0;
+}
+
+int gut_collect_times(gut_handle h, float* forward_render_ms, float* backward_render_ms) {
+    if (!h) return fail("gut_collect_times: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    const float f = drain_timers(h->fwd_timers);
+    const float b = drain_timers(h->bwd_timers);
+    if (f >= 0.f) h->last_fwd_ms = f;  // m_timings persists between calls (splatRaster.cpp:357-363)
+    if (b >= 0.f) h->last_bwd_ms = b;
+    if (forward_render_ms) *forward_render_ms = h->last_fwd_ms;
+    if (backward_render_ms) *backward_render_ms = h->last_bwd_ms;
+    return 0;
+}
+
+int gut_kernel_times(gut_handle h, float* ms8) {
+    if (!h || !ms8) return fail("gut_kernel_times: null argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    for (int i = 0; i < GUT_NUM_KERNEL_TIMERS; ++i) ms8[i] = -1.f;
+    if (!h->cfg.enable_kernel_timings) return fail("gut_kernel_times: enable_kernel_timings is off");
+    auto span = [&](int a, int b) -> float {
+        float ms = -1.f;
+        if (h->kev[a] && h->kev[b] && hipEventSynchronize(h->kev[b]) == hipSuccess) (void)hipEventElapsedTime(&ms, h->kev[a], h->kev[b]);
+        return ms;
+    };
+    if (h->kev_fwd_valid) {
+        ms8[0] = span(0, 1);  // project
+        ms8[1] = span(1, 2);  // scan (+ count readback)
+        ms8[2] = span(2, 3);  // expand
+        ms8[3] = span(3, 4);  // sort
+        ms8[4] = span(4, 5);  // ranges
+        ms8[5] = span(5, 6);  // render
+    }
+    if (h->kev_bwd_valid) {
+        ms8[6] = span(9, 10);   // render backward
+        ms8[7] = span(10, 11);  // project backward
+    }
+    return 0;
+}
+
+int gut_get_stats(gut_handle h, GutStats* out) {
+    if (!h || !out) return fail("gut_get_stats: null argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    memset(out, 0, sizeof(*out));
+    if (!h->have_forward) return fail("gut_get_stats: no forward yet");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->fwd_stream));
+    gut::Counters c;
+    HIP_TRY(hipMemcpy(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    out->num_particles = h->n;
+    out->num_visible = c.visible;
+    out->num_intersections = h->m;
+    out->num_tiles = (uint64_t)h->tiles;
+    out->num_pixels = (uint64_t)h->width * (uint64_t)h->height;
+    out->traversed_fwd = c.traversed_fwd;
+    out->traversed_bwd = c.traversed_bwd;
+    out->sort_end_bit = (uint32_t)h->end_bit;
+    return 0;
+}
+
+int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes) {
+    if (!h || !d_ptr || !bytes) return fail("gut_debug_buffer: null argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->have_forward) return fail("gut_debug_buffer: no forward yet");
+    const size_t n = h->n, m = h->m, t = (size_t)h->tiles;
+    switch (which) {
+    case GUT_BUF_TILES_COUNT: *d_ptr = h->tiles_count.p; *bytes = 4 * n; break;
+    case GUT_BUF_TILES_OFFSET: *d_ptr = h->tiles_offset.p; *bytes = 4 * n; break;
+    case GUT_BUF_PROJ_POSITION: *d_ptr = h->proj_pos.p; *bytes = 8 * n; break;
+    case GUT_BUF_CONIC_OPACITY: *d_ptr = h->conic_opacity.p; *bytes = 16 * n; break;
+    case GUT_BUF_PROJ_EXTENT: *d_ptr = h->extent.p; *bytes = 8 * n; break;
+    case GUT_BUF_GLOBAL_DEPTH: *d_ptr = h->depth.p; *bytes = 4 * n; break;
+    case GUT_BUF_FEATURES: *d_ptr = h->feat.p; *bytes = 12 * n; break;
+    case GUT_BUF_UNSORTED_KEYS: *d_ptr = h->keys_unsorted.p; *bytes = 8 * m; break;
+    case GUT_BUF_UNSORTED_IDS: *d_ptr = h->ids_unsorted.p; *bytes = 4 * m; break;
+    case GUT_BUF_SORTED_KEYS: *d_ptr = h->keys_sorted.p; *bytes = 8 * m; break;
+    case GUT_BUF_SORTED_IDS: *d_ptr = h->ids_sorted.p; *bytes = 4 * m; break;
+    case GUT_BUF_TILE_RANGES: *d_ptr = h->ranges.p; *bytes = 8 * t; break;
+    case GUT_BUF_GRAD_SCRATCH:
+        if (!h->have_backward) return fail("gut_debug_buffer: no backward yet");
+        *d_ptr = h->grad16.p; *bytes = 64 * n; break;
+    default: return fail("gut_debug_buffer: unknown buffer %d", which);
+    }
+    return 0;
+}
+
+int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes) {
+    void* src = nullptr;
+    size_t have = 0;
+    if (gut_debug_buffer(h, which, &src, &have)) return 1;
+    if (bytes < have) return fail("gut_debug_copy: destination holds %zu bytes, buffer has %zu", bytes, have);
+    if (have == 0) return 0;
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, src, have, hipMemcpyDeviceToDevice, h->fwd_stream));
+    HIP_TRY(hipStreamSynchronize(h->fwd_stream));
+    return 0;
+}
+
+}  // extern "C"

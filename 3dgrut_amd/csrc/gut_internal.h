@@ -1,0 +1,81 @@
+// gut_internal.h — types shared by the HIP translation units of libgut_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gut_hip.h"
+
+namespace gut {
+
+constexpr int kTile = 16;                 // GUTParameters::Tiling::BlockX/Y  (gutRendererParameters.h:22-31)
+constexpr int kBlock = 256;
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+// 3x4 affine transform, row-major: y = R x + t
+struct Affine {
+    float r[3][3];
+    float t[3];
+};
+
+// Everything the device code needs to know about the view; built on the host (gut_api.cpp).
+struct ViewParams {
+    Affine w2s_start;   // world->sensor at the start pose: projects the sigma points (cameraProjections.cuh:154-157)
+    Affine w2s_mid;     // world->sensor at the interpolated mid pose: depth key (gutProjector.cuh:137,317)
+    Affine s2w;         // sensor->world: ray transform; s2w.t is the sensor position in world space
+    int32_t model;
+    int32_t width, height;
+    int32_t grid_x, grid_y;
+    float principal_point[2];
+    float focal_length[2];
+    float radial[6];
+    float tangential[2];
+    float thin_prism[4];
+    float max_angle;
+};
+
+// Derived render constants (host-computed in fp32 with the same operation order as the oracle).
+struct RenderConsts {
+    float alpha_threshold, max_alpha, min_response, min_transmittance;
+    float min_sensor_z, cov_dilation;
+    float ut_delta, ut_w0_mean, ut_wi, ut_w0_cov, ut_margin;
+    int32_t rect_bounding, tight_opacity_bounding, tile_culling, global_z_order;
+    float max_d2;   // -2 ln(min_response): d2 above this can never be accepted
+};
+
+// device-side counters (one 64-byte line)
+struct Counters {
+    unsigned long long visible;        // V
+    unsigned long long traversed_fwd;  // E_f
+    unsigned long long traversed_bwd;  // E_b
+    unsigned long long pad[5];
+};
+
+// ---- launch wrappers implemented in the .hip files -------------------------------------------------
+void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, int sh_degree,
+                    const float* density12, const float* sph48, uint32_t* tiles_count, float* proj_pos,
+                    float* conic_opacity, float* extent, float* depth, float* feat, float* visibility,
+                    Counters* counters);
+void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* offset,
+                   const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
+                   uint64_t* keys, uint32_t* ids);
+void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, uint32_t* ranges);
+void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
+                        const uint32_t* tiles_count, const float* feat, const float* grad16,
+                        float* density_grad12, float* sph_grad48);
+
+void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
+                   const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
+                   const uint32_t* sorted_ids, float* rgba, float* dist, float* hits, Counters* counters);
+void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
+                       const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
+                       const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
+                       float* grad16, Counters* counters);
+
+// scan / sort (rocPRIM device-wide primitives; temp storage owned by the caller)
+size_t scan_temp_bytes(uint32_t n);
+hipError_t run_scan(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n);
+size_t sort_temp_bytes(uint32_t m, int end_bit);
+hipError_t run_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                    const uint32_t* vals_in, uint32_t* vals_out, uint32_t m, int end_bit);
+
+}  // namespace gut

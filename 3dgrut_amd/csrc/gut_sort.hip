@@ -1,0 +1,37 @@
+// gut_sort.hip — K2 (inclusive scan of tile counts) and K4 (stable radix sort of the (tile|depth) keys).
+// Reference: cub::DeviceScan::InclusiveSum / cub::DeviceRadixSort::SortPairs (src/gutRenderer.cu:302-310,
+// 356-365).  rocPRIM's device-wide primitives are the ROCm counterparts; the sort is an LSD radix sort and
+// therefore stable, restricted to key bits [0, 32 + bit_width(T)) exactly like the reference.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "gut_internal.h"
+
+namespace gut {
+
+size_t scan_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n,
+                                  rocprim::plus<uint32_t>(), (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t run_scan(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint32_t n) {
+    return rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), s);
+}
+
+size_t sort_temp_bytes(uint32_t m, int end_bit) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, (size_t)m, 0u, (unsigned int)end_bit, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t run_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                    const uint32_t* vals_in, uint32_t* vals_out, uint32_t m, int end_bit) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)m, 0u,
+                                     (unsigned int)end_bit, s);
+}
+
+}  // namespace gut

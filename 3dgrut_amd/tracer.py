@@ -1,0 +1,376 @@
+"""MI355X-native 3DGUT tracer behind the reference's plugin surface.
+
+Mirrors, name for name, what the rest of 3dgrut sees of `threedgut_tracer`:
+
+  * `Tracer(conf)`, `.render(gaussians, gpu_batch, train=False, frame_id=0) -> dict`, `.timings`,
+    `.build_acc(...)` (no-op) and the inner `Tracer._Autograd` torch.autograd.Function
+    (reference: threedgut_tracer/tracer.py:158-351);
+  * the native module surface the reference binds with pybind (bindings.cpp:79-113):
+    `SplatRaster(config).trace / .trace_bwd / .collect_times`, `ShutterType`,
+    `fromOpenCVPinholeCameraModelParameters`, `fromOpenCVFisheyeCameraModelParameters`
+    — implemented here over the C ABI of libgut_hip.so (include/gut_hip.h) with ctypes.
+
+Host code is Python on PyTorch-ROCm; PyTorch only provides device memory and the stream.  There is no
+CPU fallback: without the HIP library every call raises.
+"""
+import ctypes as C
+import enum
+import math
+
+import numpy as np
+import torch
+
+from . import _capi
+from .pose import SensorPose3D, sensor_pose_from_c2w
+
+
+# ----------------------------------------------------------------------------------------------------
+# native-module surface (lib3dgut_cc equivalent)
+# ----------------------------------------------------------------------------------------------------
+class ShutterType(enum.IntEnum):  # bindings.cpp:87-92
+    ROLLING_TOP_TO_BOTTOM = 0
+    ROLLING_LEFT_TO_RIGHT = 1
+    ROLLING_BOTTOM_TO_TOP = 2
+    ROLLING_RIGHT_TO_LEFT = 3
+    GLOBAL = 4
+
+
+class CameraModelParameters:
+    """POD camera intrinsics (sensors/cameraModels.h:22-58)."""
+
+    def __init__(self):
+        self.cam = _capi.GutCamera()
+        self.cam.shutter = int(ShutterType.GLOBAL)
+        self.cam.model = -1  # EmptyModel
+
+
+def _arr(x, n, what):
+    a = np.asarray(x, dtype=np.float32).reshape(-1)
+    if a.size != n:
+        raise RuntimeError(f"[3dgut] {what}: expected {n} values, got {a.size}")
+    return [float(v) for v in a]
+
+
+def fromOpenCVPinholeCameraModelParameters(resolution, shutter_type, principal_point, focal_length, radial_coeffs,
+                                           tangential_coeffs, thin_prism_coeffs):
+    p = CameraModelParameters()
+    p.cam.model = _capi.CAMERA_PINHOLE
+    p.cam.shutter = int(shutter_type)
+    p.cam.principal_point[:] = _arr(principal_point, 2, "principal_point")
+    p.cam.focal_length[:] = _arr(focal_length, 2, "focal_length")
+    p.cam.radial_coeffs[:] = _arr(radial_coeffs, 6, "radial_coeffs")
+    p.cam.tangential_coeffs[:] = _arr(tangential_coeffs, 2, "tangential_coeffs")
+    p.cam.thin_prism_coeffs[:] = _arr(thin_prism_coeffs, 4, "thin_prism_coeffs")
+    return p
+
+
+def fromOpenCVFisheyeCameraModelParameters(resolution, shutter_type, principal_point, focal_length, radial_coeffs,
+                                           max_angle):
+    p = CameraModelParameters()
+    p.cam.model = _capi.CAMERA_FISHEYE
+    p.cam.shutter = int(shutter_type)
+    p.cam.principal_point[:] = _arr(principal_point, 2, "principal_point")
+    p.cam.focal_length[:] = _arr(focal_length, 2, "focal_length")
+    p.cam.radial_coeffs[:] = _arr(radial_coeffs, 4, "radial_coeffs") + [0.0, 0.0]
+    p.cam.max_angle = float(max_angle)
+    return p
+
+
+def _conf_get(conf, path, default=None):
+    """conf may be an OmegaConf node, a plain nested dict or any attribute namespace."""
+    node = conf
+    for key in path.split("."):
+        if node is None:
+            return default
+        nxt = None
+        if isinstance(node, dict):
+            nxt = node.get(key, None)
+        else:
+            nxt = getattr(node, key, None)
+            if nxt is None and hasattr(node, "__getitem__"):
+                try:
+                    nxt = node[key]
+                except (KeyError, TypeError, IndexError):
+                    nxt = None
+        node = nxt
+    return default if node is None else node
+
+
+def config_from_conf(conf) -> "_capi.GutConfig":
+    """conf.render.* -> GutConfig.  The reference turns these into -D defines (setup_3dgut.py:47-70)."""
+    cfg = _capi.GutConfig()
+    _capi.load().gut_default_config(C.byref(cfg))
+    if conf is None:
+        return cfg
+    g = lambda p, d: _conf_get(conf, "render." + p, d)
+    cfg.enable_kernel_timings = int(bool(g("enable_kernel_timings", False)))
+    cfg.particle_radiance_sph_degree = int(g("particle_radiance_sph_degree", 3))
+    cfg.particle_kernel_degree = int(g("particle_kernel_degree", 2))
+    cfg.particle_kernel_min_response = float(g("particle_kernel_min_response", 0.0113))
+    cfg.particle_kernel_min_alpha = float(g("particle_kernel_min_alpha", 1.0 / 255.0))
+    cfg.particle_kernel_max_alpha = float(g("particle_kernel_max_alpha", 0.99))
+    cfg.min_transmittance = float(g("min_transmittance", 0.0001))
+    cfg.enable_hitcounts = int(bool(g("enable_hitcounts", True)))
+    cfg.n_rolling_shutter_iterations = int(g("splat.n_rolling_shutter_iterations", 5))
+    cfg.k_buffer_size = int(g("splat.k_buffer_size", 0))
+    cfg.global_z_order = int(bool(g("splat.global_z_order", True)))
+    cfg.ut_alpha = float(g("splat.ut_alpha", 1.0))
+    cfg.ut_beta = float(g("splat.ut_beta", 2.0))
+    cfg.ut_kappa = float(g("splat.ut_kappa", 0.0))
+    cfg.ut_in_image_margin_factor = float(g("splat.ut_in_image_margin_factor", 0.1))
+    cfg.ut_require_all_sigma_points = int(bool(g("splat.ut_require_all_sigma_points_valid", False)))
+    cfg.rect_bounding = int(bool(g("splat.rect_bounding", True)))
+    cfg.tight_opacity_bounding = int(bool(g("splat.tight_opacity_bounding", True)))
+    cfg.tile_based_culling = int(bool(g("splat.tile_based_culling", True)))
+    return cfg
+
+
+def _check_f32_cuda(t, name, shape_tail=None):
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
+        raise RuntimeError(f"[3dgut] {name}: expected a float32 tensor")  # cf. voidDataPtr, splatRaster.cpp:68-90
+    if not t.is_cuda:
+        raise RuntimeError(f"[3dgut] {name}: expected a GPU tensor (there is no CPU path)")
+    if shape_tail is not None and tuple(t.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise RuntimeError(f"[3dgut] {name}: expected trailing shape {shape_tail}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class SplatRaster:
+    """Drop-in for the pybind class of the same name (splatRaster.h:47-89)."""
+
+    def __init__(self, config=None, device_index=None):
+        self._lib = _capi.load()
+        self._handle = C.c_void_p()
+        cfg = config if isinstance(config, _capi.GutConfig) else config_from_conf(config)
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device_index = int(device_index)
+        self.enable_kernel_timings = bool(cfg.enable_kernel_timings)
+        _capi.check(self._lib.gut_create(C.byref(cfg), self.device_index, C.byref(self._handle)), "SplatRaster()")
+        self._timings = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None and self._handle.value:
+                self._lib.gut_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _camera(sensor_params, ts_start, ts_end, pose_start, pose_end):
+        if not isinstance(sensor_params, CameraModelParameters):
+            raise RuntimeError("[3dgut] sensor_params must come from fromOpenCV*CameraModelParameters")
+        cam = _capi.GutCamera()
+        C.memmove(C.byref(cam), C.byref(sensor_params.cam), C.sizeof(cam))
+        ps = torch.as_tensor(pose_start).detach().cpu().to(torch.float32).reshape(-1)  # toSensorState, splatRaster.cpp:92-100
+        pe = torch.as_tensor(pose_end).detach().cpu().to(torch.float32).reshape(-1)
+        if ps.numel() != 7 or pe.numel() != 7:
+            raise RuntimeError("[3dgut] sensor poses must be [t(3), q_xyzw(4)]")
+        cam.pose_start[:] = ps.tolist()
+        cam.pose_end[:] = pe.tolist()
+        cam.timestamp_start_us = int(ts_start)
+        cam.timestamp_end_us = int(ts_end)
+        return cam
+
+    def trace(self, frame_number, num_active_features, particle_density, particle_radiance, ray_ori, ray_dir, ray_time,
+              sensor_params, ts_start, ts_end, pose_start, pose_end):
+        ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
+        ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
+        if ray_ori.dim() != 4 or ray_ori.shape[0] != 1:
+            raise RuntimeError("[3dgut] rays must be [1,H,W,3] (the reference renders one view per call)")
+        H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
+        n = int(particle_density.shape[0])
+        dev = ray_ori.device
+        if n:
+            particle_density = _check_f32_cuda(particle_density, "particleDensity", (12,))
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+        opts = dict(dtype=torch.float32, device=dev)
+        rgba = torch.empty((H, W, 4), **opts)   # fully written by the kernels (no zero-fill passes)
+        dist = torch.empty((H, W, 1), **opts)
+        hits = torch.empty((H, W, 1), **opts)
+        vis = torch.empty((n, 1), **opts)
+        cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
+        stream = torch.cuda.current_stream(dev).cuda_stream  # splatRaster.cpp:186-187
+        with torch.cuda.device(dev):
+            rc = self._lib.gut_trace(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF,
+                                     int(num_active_features), n,
+                                     particle_density.data_ptr() if n else None, particle_radiance.data_ptr() if n else None,
+                                     W, H, ray_ori.data_ptr(), ray_dir.data_ptr(), C.byref(cam),
+                                     rgba.data_ptr(), dist.data_ptr(), hits.data_ptr(), vis.data_ptr() if n else None)
+        _capi.check(rc, "trace")
+        return rgba, dist, hits, vis
+
+    def trace_bwd(self, frame_number, num_active_features, particle_density, particle_radiance, ray_ori, ray_dir, ray_time,
+                  sensor_params, ts_start, ts_end, pose_start, pose_end, ray_radiance_density, ray_radiance_density_grd,
+                  ray_hit_distance, ray_hit_distance_grd):
+        ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
+        ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
+        H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
+        n = int(particle_density.shape[0])
+        dev = ray_ori.device
+        rgba = _check_f32_cuda(ray_radiance_density, "rayRadianceDensity", (4,))
+        rgba_g = _check_f32_cuda(ray_radiance_density_grd, "rayRadianceDensityGradient", (4,))
+        dist = _check_f32_cuda(ray_hit_distance, "rayHitDistance")
+        dist_g = _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
+        opts = dict(dtype=torch.float32, device=dev)
+        dens_g = torch.empty((n, 12), **opts)  # fully written by the per-Gaussian epilogue kernel
+        sph_g = torch.empty((n, 48), **opts)
+        if n:
+            particle_density = _check_f32_cuda(particle_density, "particleDensity", (12,))
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+        cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = self._lib.gut_trace_bwd(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF,
+                                         int(num_active_features), n,
+                                         particle_density.data_ptr() if n else None,
+                                         particle_radiance.data_ptr() if n else None, W, H, ray_ori.data_ptr(),
+                                         ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(), rgba_g.data_ptr(),
+                                         dist.data_ptr(), dist_g.data_ptr(), dens_g.data_ptr() if n else None,
+                                         sph_g.data_ptr() if n else None)
+        _capi.check(rc, "trace_bwd")
+        return dens_g, sph_g
+
+    def collect_times(self):
+        f, b = C.c_float(-1.0), C.c_float(-1.0)
+        _capi.check(self._lib.gut_collect_times(self._handle, C.byref(f), C.byref(b)), "collect_times")
+        if f.value >= 0:
+            self._timings["forward_render"] = f.value
+        if b.value >= 0:
+            self._timings["backward_render"] = b.value
+        return dict(self._timings)
+
+    # ---- extensions used by tests / bench (not part of the reference surface) ----
+    def stats(self):
+        s = _capi.GutStats()
+        _capi.check(self._lib.gut_get_stats(self._handle, C.byref(s)), "stats")
+        return {k: int(getattr(s, k)) for k, _ in s._fields_ if k != "reserved"}
+
+    def kernel_times(self):
+        arr = (C.c_float * _capi.GUT_NUM_KERNEL_TIMERS)()
+        _capi.check(self._lib.gut_kernel_times(self._handle, arr), "kernel_times")
+        return dict(zip(_capi.KERNEL_TIMER_NAMES, [float(v) for v in arr]))
+
+    def debug_buffer(self, name, device=None):
+        """Copy of an intermediate buffer as a torch tensor (parity tests)."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _capi.check(self._lib.gut_debug_buffer(self._handle, _capi.BUF[name], C.byref(ptr), C.byref(nbytes)), "debug_buffer")
+        dt = {"tiles_count": torch.int32, "tiles_offset": torch.int32, "unsorted_ids": torch.int32,
+              "sorted_ids": torch.int32, "tile_ranges": torch.int32, "unsorted_keys": torch.int64,
+              "sorted_keys": torch.int64}.get(name, torch.float32)
+        n = nbytes.value // (8 if dt == torch.int64 else 4)
+        dev = torch.device("cuda", self.device_index) if device is None else device
+        out = torch.empty(n, dtype=dt, device=dev)
+        if n:
+            _capi.check(self._lib.gut_debug_copy(self._handle, _capi.BUF[name], C.c_void_p(out.data_ptr()),
+                                                 C.c_size_t(nbytes.value)), "debug_copy")
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# Tracer (threedgut_tracer/tracer.py:158-431)
+# ----------------------------------------------------------------------------------------------------
+class Tracer:
+    class _Autograd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, tracer_wrapper, frame_id, n_active_features, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl,
+                    mog_dns, mog_sph, sensor_params, sensor_poses):
+            # [pos(3) | density(1) | quat wxyz(4) | scale(3) | 0] rows, tracer.py:176-178
+            particle_density = torch.cat([mog_pos, mog_dns, mog_rot, mog_scl, torch.zeros_like(mog_dns)], dim=1).contiguous()
+            particle_radiance = mog_sph.contiguous()
+            ray_time = None  # the reference allocates an int64 [1,H,W,1] tensor that no kernel reads (tracer.py:181-186)
+            rgba, dist, hits, vis = tracer_wrapper.trace(
+                frame_id, n_active_features, particle_density, particle_radiance, ray_ori.contiguous(),
+                ray_dir.contiguous(), ray_time, sensor_params, sensor_poses.timestamps_us[0], sensor_poses.timestamps_us[1],
+                sensor_poses.T_world_sensors[0], sensor_poses.T_world_sensors[1])
+            ctx.save_for_backward(ray_ori, ray_dir, rgba, dist, particle_density, particle_radiance)
+            ctx.frame_id = frame_id
+            ctx.n_active_features = n_active_features
+            ctx.sensor_params = sensor_params
+            ctx.sensor_poses = sensor_poses
+            ctx.tracer_wrapper = tracer_wrapper
+            ctx.mark_non_differentiable(hits, vis)
+            return rgba, dist, hits, vis
+
+        @staticmethod
+        def backward(ctx, rgba_grd, dist_grd, hits_grd_unused, vis_grd_unused):
+            ray_ori, ray_dir, rgba, dist, particle_density, particle_radiance = ctx.saved_tensors
+            poses = ctx.sensor_poses
+            if rgba_grd is None:
+                rgba_grd = torch.zeros_like(rgba)
+            if dist_grd is None:
+                dist_grd = torch.zeros_like(dist)
+            dens_grd, sph_grd = ctx.tracer_wrapper.trace_bwd(
+                ctx.frame_id, ctx.n_active_features, particle_density, particle_radiance, ray_ori, ray_dir, None,
+                ctx.sensor_params, poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0],
+                poses.T_world_sensors[1], rgba, rgba_grd.contiguous(), dist, dist_grd.contiguous())
+            pos_g, dns_g, rot_g, scl_g, _ = torch.split(dens_grd, [3, 1, 4, 3, 1], dim=1)  # tracer.py:268-270
+            return (None, None, None, None, None, pos_g.contiguous(), rot_g.contiguous(), scl_g.contiguous(),
+                    dns_g.contiguous(), sph_grd, None, None)
+
+    def __init__(self, conf):
+        self.device = "cuda"
+        self.conf = conf
+        torch.zeros(1, device=self.device)  # force context creation (tracer.py:292)
+        self.tracer_wrapper = SplatRaster(conf)
+
+    @property
+    def timings(self):
+        return self.tracer_wrapper.collect_times()
+
+    def build_acc(self, gaussians, rebuild=True):
+        pass  # no acceleration structure in 3DGUT (tracer.py:301-302)
+
+    def render(self, gaussians, gpu_batch, train=False, frame_id=0):
+        rays_o = gpu_batch.rays_ori
+        rays_d = gpu_batch.rays_dir
+        sensor, poses = Tracer.create_camera_parameters(gpu_batch)
+        pred_rgba, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
+            self.tracer_wrapper, frame_id, gaussians.n_active_features, rays_o.contiguous(), rays_d.contiguous(),
+            gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
+            gaussians.get_density().contiguous(), gaussians.get_features().contiguous(), sensor, poses)
+        pred_rgb = pred_rgba[..., :3].unsqueeze(0).contiguous()
+        pred_opacity = pred_rgba[..., 3:].unsqueeze(0).contiguous()
+        pred_dist = pred_dist.unsqueeze(0).contiguous()
+        hits_count = hits_count.unsqueeze(0).contiguous()
+        pred_rgb, pred_opacity = gaussians.background(gpu_batch.T_to_world.contiguous(), rays_d, pred_rgb, pred_opacity, train)
+        timings = self.tracer_wrapper.collect_times()
+        return {
+            "pred_rgb": pred_rgb,
+            "pred_opacity": pred_opacity,
+            "pred_dist": pred_dist,
+            "pred_normals": torch.nn.functional.normalize(torch.ones_like(pred_rgb), dim=3),
+            "hits_count": hits_count,
+            "frame_time_ms": timings["forward_render"] if "forward_render" in timings else 0.0,
+            "mog_visibility": mog_visibility,
+        }
+
+    @staticmethod
+    def create_camera_parameters(gpu_batch):
+        """Batch -> (CameraModelParameters, SensorPose3D); tracer.py:361-431."""
+        pose = gpu_batch.T_to_world.squeeze()
+        assert pose.ndim == 2
+        poses = sensor_pose_from_c2w(pose.detach().cpu().numpy())
+        if (K := getattr(gpu_batch, "intrinsics", None)) is not None:
+            fx, fy, cx, cy = (float(K[0]), float(K[1]), float(K[2]), float(K[3]))
+            w, h = int(2 * cx), int(2 * cy)
+            # focal -> fov -> focal round trip in Python floats, exactly as tracer.py:386-403
+            fov_x, fov_y = 2 * math.atan(w / (2 * fx)), 2 * math.atan(h / (2 * fy))
+            return fromOpenCVPinholeCameraModelParameters(
+                resolution=np.array([w, h], dtype=np.uint64), shutter_type=ShutterType.GLOBAL,
+                principal_point=np.array([w, h], dtype=np.float32) / 2,
+                focal_length=np.array([w / (2.0 * math.tan(fov_x * 0.5)), h / (2.0 * math.tan(fov_y * 0.5))], dtype=np.float32),
+                radial_coeffs=np.zeros((6,), dtype=np.float32), tangential_coeffs=np.zeros((2,), dtype=np.float32),
+                thin_prism_coeffs=np.zeros((4,), dtype=np.float32)), poses
+        if (K := getattr(gpu_batch, "intrinsics_OpenCVPinholeCameraModelParameters", None)) is not None:
+            return fromOpenCVPinholeCameraModelParameters(
+                resolution=K["resolution"], shutter_type=ShutterType(int(K["shutter_type"])),
+                principal_point=K["principal_point"], focal_length=K["focal_length"], radial_coeffs=K["radial_coeffs"],
+                tangential_coeffs=K["tangential_coeffs"], thin_prism_coeffs=K["thin_prism_coeffs"]), poses
+        if (K := getattr(gpu_batch, "intrinsics_OpenCVFisheyeCameraModelParameters", None)) is not None:
+            return fromOpenCVFisheyeCameraModelParameters(
+                resolution=K["resolution"], shutter_type=ShutterType(int(K["shutter_type"])),
+                principal_point=K["principal_point"], focal_length=K["focal_length"], radial_coeffs=K["radial_coeffs"],
+                max_angle=K["max_angle"]), poses
+        raise ValueError("Camera intrinsics unavailable or unsupported")

@@ -1,0 +1,166 @@
+/*
+ * gut_hip.h — C ABI of libgut_hip.so, the MI355X-native replacement of the reference's pybind
+ * module `lib3dgut_cc` (threedgut_tracer/bindings.cpp:79-113, include/3dgut/splatRaster.h:47-89).
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller (torch tensors in the Python
+ *     shim); the library never retains them past the call.  Scratch (per-Gaussian projection
+ *     buffers, tile keys, sort temporaries) is owned by the handle and is grow-only.
+ *   - `stream` is a hipStream_t passed as void*; all work of a call is enqueued on it.  trace() does
+ *     one 4-byte device->host readback + stream synchronise (the intersection count), exactly like
+ *     the reference (src/gutRenderer.cu:313-321).
+ *   - return value 0 = success; anything else is an error and gut_last_error() describes it
+ *     (the reference logs and drops its Status codes, splatRaster.cpp:225-237; pybind turns C++
+ *     exceptions into RuntimeError — the Python shim raises RuntimeError on non-zero).
+ *   - one handle <-> one in-flight view: trace_bwd() must follow the trace() it differentiates, on
+ *     the same stream (gutRenderer.cu:413-417).  A handle may be used from different host threads
+ *     (autograd worker) but not concurrently.
+ */
+#ifndef GUT_HIP_H
+#define GUT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GUT_ABI_VERSION 1
+
+typedef struct gut_context* gut_handle;
+
+/* sensors/cameraModels.h:34-47 */
+enum { GUT_SHUTTER_ROLLING_TOP_TO_BOTTOM = 0, GUT_SHUTTER_ROLLING_LEFT_TO_RIGHT = 1,
+       GUT_SHUTTER_ROLLING_BOTTOM_TO_TOP = 2, GUT_SHUTTER_ROLLING_RIGHT_TO_LEFT = 3, GUT_SHUTTER_GLOBAL = 4 };
+enum { GUT_CAMERA_OPENCV_PINHOLE = 0, GUT_CAMERA_OPENCV_FISHEYE = 1 };
+
+/* Replaces threedgut::CameraModelParameters + TSensorState (sensors/cameraModels.h:22-58,
+ * sensors/sensors.h:33-42) as built by fromOpenCV{Pinhole,Fisheye}CameraModelParameters
+ * (bindings.cpp:34-77) and toSensorState (splatRaster.cpp:92-100). */
+typedef struct GutCamera {
+    int32_t model;              /* GUT_CAMERA_* */
+    int32_t shutter;            /* GUT_SHUTTER_* (only GLOBAL is implemented in this round) */
+    float principal_point[2];
+    float focal_length[2];
+    float radial_coeffs[6];     /* pinhole: k1..k6 ; fisheye: k1..k4 in [0..3] */
+    float tangential_coeffs[2]; /* pinhole only */
+    float thin_prism_coeffs[4]; /* pinhole only */
+    float max_angle;            /* fisheye only */
+    float pose_start[7];        /* world->sensor translation (3) + quaternion (x,y,z,w) */
+    float pose_end[7];
+    int64_t timestamp_start_us;
+    int64_t timestamp_end_us;
+} GutCamera;
+
+/* The reference bakes conf.render.* into the kernels as -D defines (setup_3dgut.py:47-70) and its
+ * SplatRaster constructor reads only render.enable_kernel_timings (splatRaster.cpp:158-159).  Here
+ * the same settings arrive as a struct; combinations other than the precompiled default variant
+ * are rejected by gut_create with a clear message. */
+typedef struct GutConfig {
+    int32_t abi_version;                  /* GUT_ABI_VERSION */
+    int32_t enable_kernel_timings;        /* render.enable_kernel_timings */
+    int32_t particle_radiance_sph_degree; /* 3  -> 16 coefficients */
+    int32_t particle_kernel_degree;       /* 2 (quadratic) */
+    int32_t k_buffer_size;                /* 0 (unsorted) */
+    int32_t global_z_order;               /* 1 */
+    int32_t n_rolling_shutter_iterations; /* 5 (unused: global shutter only) */
+    int32_t ut_require_all_sigma_points;  /* 0 */
+    int32_t rect_bounding, tight_opacity_bounding, tile_based_culling; /* 1,1,1 */
+    int32_t enable_hitcounts;             /* 1 */
+    float particle_kernel_min_response;   /* 0.0113 */
+    float particle_kernel_min_alpha;      /* 1/255 */
+    float particle_kernel_max_alpha;      /* 0.99 */
+    float min_transmittance;              /* 1e-4 */
+    float ut_alpha, ut_beta, ut_kappa;    /* 1, 2, 0 */
+    float ut_in_image_margin_factor;      /* 0.1 */
+} GutConfig;
+
+/* scene/traversal statistics of the most recent trace()/trace_bwd() pair: the quantities the
+ * algorithmic-bytes model of SURVEY.md §8d is written in. */
+typedef struct GutStats {
+    uint64_t num_particles;      /* N */
+    uint64_t num_visible;        /* V : Gaussians with tilesCount > 0 */
+    uint64_t num_intersections;  /* M */
+    uint64_t num_tiles;          /* T */
+    uint64_t num_pixels;         /* P */
+    uint64_t traversed_fwd;      /* E_f : sum over tiles of list entries fetched before the tile terminated */
+    uint64_t traversed_bwd;      /* E_b */
+    uint32_t sort_end_bit;       /* 32 + bit_width(T) */
+    uint32_t reserved;
+} GutStats;
+
+/* intermediate buffers exposed to the parity tests (device pointers into handle scratch, valid until
+ * the next trace() on the handle) */
+enum {
+    GUT_BUF_TILES_COUNT = 0,   /* u32 [N]        gutRenderer.cu:166 */
+    GUT_BUF_TILES_OFFSET = 1,  /* u32 [N]        inclusive scan */
+    GUT_BUF_PROJ_POSITION = 2, /* f32 [N,2] */
+    GUT_BUF_CONIC_OPACITY = 3, /* f32 [N,4] */
+    GUT_BUF_PROJ_EXTENT = 4,   /* f32 [N,2] */
+    GUT_BUF_GLOBAL_DEPTH = 5,  /* f32 [N] */
+    GUT_BUF_FEATURES = 6,      /* f32 [N,3] precomputed view-dependent RGB (unclamped) */
+    GUT_BUF_UNSORTED_KEYS = 7, /* u64 [M] */
+    GUT_BUF_UNSORTED_IDS = 8,  /* u32 [M] */
+    GUT_BUF_SORTED_KEYS = 9,   /* u64 [M] */
+    GUT_BUF_SORTED_IDS = 10,   /* u32 [M] */
+    GUT_BUF_TILE_RANGES = 11,  /* u32 [T,2] */
+    GUT_BUF_GRAD_SCRATCH = 12  /* f32 [N,16] per-Gaussian gradient rows of the last trace_bwd */
+};
+
+/* fills *cfg with the reference defaults (configs/render/3dgut.yaml + 3dgrt.yaml) */
+void gut_default_config(GutConfig* cfg);
+
+/* SplatRaster(json) — splatRaster.cpp:153-169 */
+int gut_create(const GutConfig* cfg, int device_index, gut_handle* out);
+/* ~SplatRaster */
+void gut_destroy(gut_handle h);
+
+/* SplatRaster::trace — splatRaster.cpp:174-245.
+ *   d_particle_density  f32 [N,12]  (pos3, density, quat wxyz, scale3, pad)   tracer.py:176-178
+ *   d_particle_radiance f32 [N,48]  (16 SH coefficients x RGB)
+ *   d_ray_origin/d_ray_direction f32 [H,W,3] camera-space rays
+ * outputs (fully written by the call, no pre-initialisation needed):
+ *   d_ray_radiance_density f32 [H,W,4], d_ray_hit_distance f32 [H,W,1] (1e6 for rays that miss the
+ *   scene AABB), d_ray_hit_count f32 [H,W,1], d_particle_visibility f32 [N,1] (1.0/0.0)          */
+int gut_trace(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features /* SH degree 0..3 */,
+              uint32_t num_particles, const float* d_particle_density, const float* d_particle_radiance,
+              int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
+              const GutCamera* camera,
+              float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+              float* d_particle_visibility);
+
+/* SplatRaster::traceBwd — splatRaster.cpp:247-332.  Gradient outputs are fully overwritten:
+ *   d_particle_density_grad f32 [N,12], d_particle_radiance_grad f32 [N,48]                       */
+int gut_trace_bwd(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features,
+                  uint32_t num_particles, const float* d_particle_density, const float* d_particle_radiance,
+                  int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
+                  const GutCamera* camera,
+                  const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                  const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad,
+                  float* d_particle_density_grad, float* d_particle_radiance_grad);
+
+/* SplatRaster::collectTimes — splatRaster.cpp:334-364: mean ms per tag over the timers recorded
+ * since the last call; -1 for a tag with no samples. */
+int gut_collect_times(gut_handle h, float* forward_render_ms, float* backward_render_ms);
+
+/* statistics + debug views (parity tests, roofline accounting).  gut_get_stats synchronises the
+ * stream of the last call. */
+int gut_get_stats(gut_handle h, GutStats* out);
+int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes);
+/* copies a debug buffer into caller-owned DEVICE memory of at least `bytes` bytes (stream-ordered, then synchronised) */
+int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
+
+/* per-kernel hipEvent timings of the last trace / trace_bwd (ms), for bench.py's roofline block.
+ * Order: project, scan, expand, sort, ranges, render, render_bwd, project_bwd.  Requires
+ * enable_kernel_timings; synchronises. */
+#define GUT_NUM_KERNEL_TIMERS 8
+int gut_kernel_times(gut_handle h, float* ms8);
+
+const char* gut_last_error(void);
+int gut_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GUT_HIP_H */

@@ -1,0 +1,217 @@
+"""GPU parity: libgut_hip.so (through the C ABI, via the Tracer/SplatRaster mirror) vs the CPU oracle.
+
+Bar (BASELINE.json north_star): integer tile/key buffers bit-exact; colour buffers within a stated fp32
+tolerance.  Tolerances used here:
+  * projection floats (position, conic, extent, depth, precomputed RGB): bit-exact (shared numerics contract);
+  * rgba: max |diff| <= 2e-4 (the compositor uses v_exp/v_rcp/v_rsq hardware approximations, ~1 ulp each,
+    and FMA contraction; the oracle uses glibc expf without contraction);
+  * hit count: may differ where a response sits within 1e-6 of the 0.0113 / 1/255 thresholds: <= 0.1 % pixels;
+  * gradients: relative L2 error <= 2e-3 per parameter block against the oracle's double-accumulated sums
+    (the GPU sums fp32 partials in a hardware-dependent tree/atomic order).
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import cams, make_view, rel_l2, scenes, to_batch
+
+pytestmark = pytest.mark.gpu
+
+gut = importlib.import_module("3dgrut_amd")
+oracle = importlib.import_module("oracle.oracle")
+DEV = "cuda:0"
+
+DIST = dict(radial=[0.05, -0.02, 0.003, 0.01, 0.002, -0.001], tangential=[0.002, -0.001], thin_prism=[0.001, 0.0, -0.0005, 0.0])
+
+CASES = {
+    # name: (scene fn, view kind, W, H, camera, kwargs)
+    "c1_pinhole_128": (lambda: scenes.scene_c1(1000, 0), "pinhole", 128, 128, ((0, 0, -4), (0, 0, 0)), dict(fx=128)),
+    "c1_list_intrinsics": (lambda: scenes.scene_c1(1000, 0), "pinhole_list", 128, 128, ((0, 0, -4), (0, 0, 0)), dict(fx=128)),
+    "ragged_100x70": (lambda: scenes.scene_c1(700, 3), "pinhole", 100, 70, ((0.5, -0.3, -3.0), (0, 0.1, 0)), dict(fx=90, fy=95)),
+    "distorted_pinhole": (lambda: scenes.scene_c1(800, 4), "pinhole", 160, 96, ((0.2, 0.1, -3.2), (0, 0, 0)), dict(fx=120, distortion=DIST)),
+    "fisheye_144x96": (lambda: scenes.scene_c1(900, 5), "fisheye", 144, 96, ((0.1, 0.0, -1.5), (0, 0, 0.5)), dict()),
+    "inside_cloud": (lambda: scenes.scene_c1(1500, 6), "pinhole", 96, 96, ((0.05, 0.02, -0.1), (0, 0, 1)), dict(fx=60)),
+    "dense_big_splats": (lambda: _big(), "pinhole", 64, 64, ((0, 0, -3), (0, 0, 0)), dict(fx=64)),
+}
+
+
+def _big():
+    sc = scenes.scene_c1(400, 7)
+    sc["scale"] = (sc["scale"] * 4.0).astype(np.float32)
+    sc["density"] = np.clip(sc["density"] * 1.5, 0, 0.999).astype(np.float32)
+    return sc
+
+
+def _run_gpu(sc, view, sh_degree, rgba_grad=None, dist_grad=None, timings=False):
+    model = gut_model(sc, sh_degree)
+    tr = gut.Tracer({"render": {"enable_kernel_timings": timings}})
+    batch = to_batch(view, DEV)
+    out = tr.render(model, batch, train=True, frame_id=0)
+    res = dict(out=out, tracer=tr, model=model)
+    if rgba_grad is not None:
+        rg = torch.as_tensor(rgba_grad, device=DEV)
+        loss = (out["pred_rgb"][0] * rg[..., :3]).sum() + (out["pred_opacity"][0] * rg[..., 3:]).sum()
+        if dist_grad is not None:
+            loss = loss + (out["pred_dist"][0] * torch.as_tensor(dist_grad, device=DEV)).sum()
+        loss.backward()
+    return res
+
+
+def gut_model(sc, sh_degree):
+    m = importlib.import_module("3dgrut_amd.model")
+    return m.GaussianModel(sc, device=DEV, sh_degree=sh_degree)
+
+
+def _activated_grads(model, dens_g, sph_g):
+    """Oracle grads are w.r.t. the activated tracer inputs; chain them through the same activations in float64
+    so they are comparable with the nn.Parameter grads autograd produced on the GPU."""
+    with torch.enable_grad():
+        raw = {k: getattr(model, k).detach().double().cpu().requires_grad_(True)
+               for k in ("positions", "rotation", "scale", "density", "features_albedo", "features_specular")}
+        rot = torch.nn.functional.normalize(raw["rotation"], dim=1)
+        scl = torch.exp(raw["scale"])
+        dns = torch.sigmoid(raw["density"])
+        feats = torch.cat([raw["features_albedo"], raw["features_specular"]], 1)
+        dg = torch.as_tensor(dens_g)
+        tot = (raw["positions"] * dg[:, 0:3]).sum() + (dns * dg[:, 3:4]).sum() + (rot * dg[:, 4:8]).sum() + \
+              (scl * dg[:, 8:11]).sum() + (feats * torch.as_tensor(sph_g)).sum()
+        tot.backward()
+    return {k: v.grad.numpy() for k, v in raw.items()}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_buffers_and_image(name):
+    mk, kind, W, H, (eye, tgt), kw = CASES[name]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    sh = 3
+    ref = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=sh)
+    res = _run_gpu(sc, view, sh)
+    raster = res["tracer"].tracer_wrapper
+    st = raster.stats()
+    assert st["num_intersections"] == ref["M"]
+    assert st["num_visible"] == int((ref["tiles_count"] > 0).sum())
+    assert st["sort_end_bit"] == ref["end_bit"]
+    # integer structure: exact
+    for key in ("tiles_count", "tiles_offset", "unsorted_ids", "sorted_ids"):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, ref[key]), key
+    for key in ("unsorted_keys", "sorted_keys"):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, ref[key]), key
+    got = raster.debug_buffer("tile_ranges").cpu().numpy().view(np.uint32).reshape(-1, 2)
+    assert np.array_equal(got, ref["tile_ranges"])
+    # projection floats: bit-exact under the shared numerics contract
+    for key, refkey in (("proj_pos", "proj_pos"), ("conic_opacity", "conic_opacity"), ("extent", "extent"), ("depth", "depth"),
+                        ("feat", "feat")):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
+        exp = np.ascontiguousarray(ref[refkey]).reshape(-1).view(np.uint32)
+        assert np.array_equal(got, exp), f"{key}: {(got != exp).sum()} of {got.size} words differ"
+    vis = res["out"]["mog_visibility"].cpu().numpy()[:, 0]
+    assert np.array_equal(vis > 0, ref["visibility"] > 0)
+    # image
+    rgb = res["out"]["pred_rgb"][0].cpu().numpy()
+    op = res["out"]["pred_opacity"][0].cpu().numpy()
+    assert np.abs(rgb - ref["rgba"][..., :3]).max() <= 2e-4
+    assert np.abs(op - ref["rgba"][..., 3:]).max() <= 2e-4
+    d = res["out"]["pred_dist"][0].cpu().numpy()
+    assert np.abs(d - ref["dist"]).max() <= 2e-4 * max(1.0, float(np.abs(ref["dist"]).max()))
+    hits = res["out"]["hits_count"][0].cpu().numpy()
+    assert (hits != ref["hits"]).mean() <= 1e-3
+    assert st["traversed_fwd"] == ref["traversed_fwd"]
+
+
+@pytest.mark.parametrize("name", ["c1_pinhole_128", "ragged_100x70", "fisheye_144x96", "dense_big_splats", "inside_cloud"])
+@pytest.mark.parametrize("with_dist_grad", [False, True])
+def test_backward_gradients(name, with_dist_grad):
+    mk, kind, W, H, (eye, tgt), kw = CASES[name]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    rng = np.random.default_rng(11)
+    rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
+    dist_grad = (0.1 * rng.normal(size=(H, W, 1))).astype(np.float32) if with_dist_grad else None
+    ref = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=3)
+    dens_g, sph_g, feat_g = oracle.backward(view["oracle_cam"], ref, rgba_grad,
+                                            dist_grad if with_dist_grad else np.zeros((H, W, 1), np.float32))
+    res = _run_gpu(sc, view, 3, rgba_grad=rgba_grad, dist_grad=dist_grad)
+    model = res["model"]
+    exp = _activated_grads(model, dens_g, sph_g)
+    for k, e in exp.items():
+        g = getattr(model, k).grad.cpu().numpy()
+        err = rel_l2(g, e)
+        assert err <= 2e-3, f"{name}/{k}: rel L2 {err}"
+    st = res["tracer"].tracer_wrapper.stats()
+    assert st["traversed_bwd"] == ref["traversed_bwd"]
+
+
+@pytest.mark.parametrize("sh", [0, 1, 2])
+def test_lower_sh_degrees(sh):
+    sc = scenes.scene_c1(600, 9)
+    view = make_view("pinhole", 80, 64, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=80)
+    W, H = 80, 64
+    rgba_grad = np.random.default_rng(1).normal(size=(H, W, 4)).astype(np.float32)
+    ref = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=sh)
+    dens_g, sph_g, _ = oracle.backward(view["oracle_cam"], ref, rgba_grad, np.zeros((H, W, 1), np.float32))
+    res = _run_gpu(sc, view, sh, rgba_grad=rgba_grad)
+    rgb = res["out"]["pred_rgb"][0].detach().cpu().numpy()
+    assert np.abs(rgb - ref["rgba"][..., :3]).max() <= 2e-4
+    exp = _activated_grads(res["model"], dens_g, sph_g)
+    g = res["model"].features_specular.grad.cpu().numpy()
+    nc = (sh + 1) ** 2
+    assert np.all(g[:, 3 * (nc - 1):] == 0), "coefficients above the active degree must get zero gradient"
+    assert rel_l2(res["model"].features_albedo.grad.cpu().numpy(), exp["features_albedo"]) <= 2e-3
+    if sh:
+        assert rel_l2(g, exp["features_specular"]) <= 2e-3
+
+
+def test_empty_and_culled_scenes():
+    view = make_view("pinhole", 64, 48, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64)
+    raster = gut.SplatRaster({"render": {}})
+    sensor, poses = gut.Tracer.create_camera_parameters(to_batch(view, DEV))
+    ro = torch.as_tensor(view["ro"], device=DEV); rd = torch.as_tensor(view["rd"], device=DEV)
+    # N = 0
+    rgba, dist, hits, vis = raster.trace(0, 3, torch.zeros((0, 12), device=DEV), torch.zeros((0, 48), device=DEV), ro, rd, None,
+                                         sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
+    assert float(rgba.abs().max()) == 0 and float((dist - 1e6).abs().max()) == 0 and float(hits.abs().max()) == 0 and vis.shape == (0, 1)
+    # everything behind the camera: M = 0 -> outputs keep the reference's initial values for valid rays: zeros / 0 dist
+    sc = scenes.scene_c1(200, 1)
+    sc["positions"][:, 2] -= 20.0
+    d12 = torch.as_tensor(scenes.pack_density(sc), device=DEV); sph = torch.as_tensor(sc["features"], device=DEV)
+    rgba, dist, hits, vis = raster.trace(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
+    assert raster.stats()["num_intersections"] == 0
+    assert float(rgba.abs().max()) == 0 and float(hits.abs().max()) == 0 and float(vis.abs().max()) == 0
+    dg, sg = raster.trace_bwd(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1],
+                              rgba, torch.ones_like(rgba), dist, torch.zeros_like(dist))
+    assert float(dg.abs().max()) == 0 and float(sg.abs().max()) == 0
+
+
+def test_error_behaviour():
+    raster = gut.SplatRaster({"render": {}})
+    view = make_view("pinhole", 32, 32, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=32)
+    sensor, poses = gut.Tracer.create_camera_parameters(to_batch(view, DEV))
+    ro = torch.as_tensor(view["ro"], device=DEV); rd = torch.as_tensor(view["rd"], device=DEV)
+    d12 = torch.zeros((4, 12), device=DEV); sph = torch.zeros((4, 48), device=DEV)
+    with pytest.raises(RuntimeError):  # backward before any forward
+        raster.trace_bwd(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1],
+                         torch.zeros((32, 32, 4), device=DEV), torch.zeros((32, 32, 4), device=DEV),
+                         torch.zeros((32, 32, 1), device=DEV), torch.zeros((32, 32, 1), device=DEV))
+    with pytest.raises(RuntimeError):  # wrong dtype (voidDataPtr throws in the reference, splatRaster.cpp:86)
+        raster.trace(0, 3, d12.double(), sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
+    with pytest.raises(RuntimeError):  # unsupported variant is rejected, not silently rendered
+        gut.SplatRaster({"render": {"splat": {"k_buffer_size": 16}}})
+    sensor.cam.shutter = 0
+    with pytest.raises(RuntimeError):
+        raster.trace(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
+
+
+def test_timings_surface():
+    sc = scenes.scene_c1(500, 2)
+    view = make_view("pinhole", 64, 64, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64)
+    res = _run_gpu(sc, view, 3, rgba_grad=np.ones((64, 64, 4), np.float32), timings=True)
+    assert res["out"]["frame_time_ms"] > 0
+    t = res["tracer"].timings
+    assert t["forward_render"] > 0 and t["backward_render"] > 0
+    kt = res["tracer"].tracer_wrapper.kernel_times()
+    assert all(kt[k] >= 0 for k in ("project", "sort", "render", "render_bwd", "project_bwd"))
