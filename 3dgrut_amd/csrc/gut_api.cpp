@@ -390,7 +390,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     // with zero intersections the reference returns its freshly initialised outputs (gutRenderer.cu:323-325);
     // running the compositor over empty ranges writes exactly those values
     gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
-                       h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_ray_radiance_density, d_ray_hit_distance,
+                       h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, d_ray_radiance_density, d_ray_hit_distance,
                        d_ray_hit_count, h->counters.as<gut::Counters>());
     mark(6);
     HIP_TRY(hipGetLastError());

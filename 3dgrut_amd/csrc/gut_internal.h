@@ -65,7 +65,8 @@ void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_d
 
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
-                   const uint32_t* sorted_ids, float* rgba, float* dist, float* hits, Counters* counters);
+                   const uint32_t* sorted_ids, uint32_t num_intersections, float* rgba, float* dist, float* hits,
+                   Counters* counters);
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,

@@ -119,9 +119,9 @@ struct FwdEntry {      // 80 bytes, 16-byte aligned: five ds_read_b128 broadcast
 __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c, const float4* __restrict__ density12,
                                                   const float* __restrict__ feat, const float* __restrict__ ray_ori,
                                                   const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
-                                                  const uint32_t* __restrict__ sorted_ids, float4* __restrict__ rgba,
-                                                  float* __restrict__ dist, float* __restrict__ hits,
-                                                  Counters* __restrict__ counters) {
+                                                  const uint32_t* __restrict__ sorted_ids, uint32_t num_intersections,
+                                                  float4* __restrict__ rgba, float* __restrict__ dist,
+                                                  float* __restrict__ hits, Counters* __restrict__ counters) {
     __shared__ FwdEntry stage[kBlock];
     __shared__ uint32_t s_deepest;
 
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
     const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + (int)(tid >> 4);
     const bool inside = (px < v.width) && (py < v.height);
     const size_t pix = (size_t)py * (size_t)v.width + (size_t)px;
-    const RayState ray = make_ray(v, ray_ori, ray_dir, pix, inside);
+    // zero intersections: the reference returns before rendering and the outputs keep their initial values
+    // (gutRenderer.cu:323-325); treating every ray as invalid writes exactly those
+    const RayState ray = make_ray(v, ray_ori, ray_dir, pix, inside && (num_intersections != 0));
 
     if (tid == 0) s_deepest = 0;
 
@@ -476,12 +478,12 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
 // ---------------------------------------------------------------------------------------------------
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                   float* rgba, float* dist, float* hits, Counters* counters) {
+                   uint32_t num_intersections, float* rgba, float* dist, float* hits, Counters* counters) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     hipLaunchKernelGGL(k_render, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12), feat,
-                       ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, reinterpret_cast<float4*>(rgba),
-                       dist, hits, counters);
+                       ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, num_intersections,
+                       reinterpret_cast<float4*>(rgba), dist, hits, counters);
 }
 
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,

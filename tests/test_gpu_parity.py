@@ -44,12 +44,25 @@ def _big():
     return sc
 
 
-def _run_gpu(sc, view, sh_degree, rgba_grad=None, dist_grad=None, timings=False):
+def _oracle_inputs(sc, sh_degree=3):
+    """Activated parameters exactly as the GPU model produces them (oracle and GPU must see identical bits)."""
     model = gut_model(sc, sh_degree)
+    with torch.no_grad():
+        d12 = torch.cat([model.positions, model.get_density(), model.get_rotation(), model.get_scale(),
+                         torch.zeros_like(model.get_density())], 1).cpu().numpy()
+        return model, d12, model.get_features().cpu().numpy()
+
+
+def _run_gpu(sc, view, sh_degree, rgba_grad=None, dist_grad=None, timings=False, model=None):
+    model = model if model is not None else gut_model(sc, sh_degree)
     tr = gut.Tracer({"render": {"enable_kernel_timings": timings}})
     batch = to_batch(view, DEV)
     out = tr.render(model, batch, train=True, frame_id=0)
     res = dict(out=out, tracer=tr, model=model)
+    with torch.no_grad():  # the exact activated tensors the tracer consumed (exp(log(s)) != s in fp32)
+        res["density12"] = torch.cat([model.positions, model.get_density(), model.get_rotation(), model.get_scale(),
+                                      torch.zeros_like(model.get_density())], 1).cpu().numpy()
+        res["sph48"] = model.get_features().cpu().numpy()
     if rgba_grad is not None:
         rg = torch.as_tensor(rgba_grad, device=DEV)
         loss = (out["pred_rgb"][0] * rg[..., :3]).sum() + (out["pred_opacity"][0] * rg[..., 3:]).sum()
@@ -87,8 +100,9 @@ def test_forward_buffers_and_image(name):
     sc = mk()
     view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
     sh = 3
-    ref = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=sh)
-    res = _run_gpu(sc, view, sh)
+    model, d12, sph = _oracle_inputs(sc, sh)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=sh)
+    res = _run_gpu(sc, view, sh, model=model)
     raster = res["tracer"].tracer_wrapper
     st = raster.stats()
     assert st["num_intersections"] == ref["M"]
@@ -109,16 +123,16 @@ def test_forward_buffers_and_image(name):
         got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
         exp = np.ascontiguousarray(ref[refkey]).reshape(-1).view(np.uint32)
         assert np.array_equal(got, exp), f"{key}: {(got != exp).sum()} of {got.size} words differ"
-    vis = res["out"]["mog_visibility"].cpu().numpy()[:, 0]
+    vis = res["out"]["mog_visibility"].detach().cpu().numpy()[:, 0]
     assert np.array_equal(vis > 0, ref["visibility"] > 0)
     # image
-    rgb = res["out"]["pred_rgb"][0].cpu().numpy()
-    op = res["out"]["pred_opacity"][0].cpu().numpy()
+    rgb = res["out"]["pred_rgb"][0].detach().cpu().numpy()
+    op = res["out"]["pred_opacity"][0].detach().cpu().numpy()
     assert np.abs(rgb - ref["rgba"][..., :3]).max() <= 2e-4
     assert np.abs(op - ref["rgba"][..., 3:]).max() <= 2e-4
-    d = res["out"]["pred_dist"][0].cpu().numpy()
+    d = res["out"]["pred_dist"][0].detach().cpu().numpy()
     assert np.abs(d - ref["dist"]).max() <= 2e-4 * max(1.0, float(np.abs(ref["dist"]).max()))
-    hits = res["out"]["hits_count"][0].cpu().numpy()
+    hits = res["out"]["hits_count"][0].detach().cpu().numpy()
     assert (hits != ref["hits"]).mean() <= 1e-3
     assert st["traversed_fwd"] == ref["traversed_fwd"]
 
@@ -132,10 +146,11 @@ def test_backward_gradients(name, with_dist_grad):
     rng = np.random.default_rng(11)
     rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
     dist_grad = (0.1 * rng.normal(size=(H, W, 1))).astype(np.float32) if with_dist_grad else None
-    ref = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=3)
+    model0, d12, sph = _oracle_inputs(sc, 3)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
     dens_g, sph_g, feat_g = oracle.backward(view["oracle_cam"], ref, rgba_grad,
                                             dist_grad if with_dist_grad else np.zeros((H, W, 1), np.float32))
-    res = _run_gpu(sc, view, 3, rgba_grad=rgba_grad, dist_grad=dist_grad)
+    res = _run_gpu(sc, view, 3, rgba_grad=rgba_grad, dist_grad=dist_grad, model=model0)
     model = res["model"]
     exp = _activated_grads(model, dens_g, sph_g)
     for k, e in exp.items():
@@ -152,9 +167,10 @@ def test_lower_sh_degrees(sh):
     view = make_view("pinhole", 80, 64, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=80)
     W, H = 80, 64
     rgba_grad = np.random.default_rng(1).normal(size=(H, W, 4)).astype(np.float32)
-    ref = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=sh)
+    model0, d12, sph = _oracle_inputs(sc, sh)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=sh)
     dens_g, sph_g, _ = oracle.backward(view["oracle_cam"], ref, rgba_grad, np.zeros((H, W, 1), np.float32))
-    res = _run_gpu(sc, view, sh, rgba_grad=rgba_grad)
+    res = _run_gpu(sc, view, sh, rgba_grad=rgba_grad, model=model0)
     rgb = res["out"]["pred_rgb"][0].detach().cpu().numpy()
     assert np.abs(rgb - ref["rgba"][..., :3]).max() <= 2e-4
     exp = _activated_grads(res["model"], dens_g, sph_g)
@@ -175,13 +191,14 @@ def test_empty_and_culled_scenes():
     rgba, dist, hits, vis = raster.trace(0, 3, torch.zeros((0, 12), device=DEV), torch.zeros((0, 48), device=DEV), ro, rd, None,
                                          sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
     assert float(rgba.abs().max()) == 0 and float((dist - 1e6).abs().max()) == 0 and float(hits.abs().max()) == 0 and vis.shape == (0, 1)
-    # everything behind the camera: M = 0 -> outputs keep the reference's initial values for valid rays: zeros / 0 dist
+    # everything behind the camera: M = 0 -> the reference returns before rendering, outputs keep their initial values
     sc = scenes.scene_c1(200, 1)
     sc["positions"][:, 2] -= 20.0
     d12 = torch.as_tensor(scenes.pack_density(sc), device=DEV); sph = torch.as_tensor(sc["features"], device=DEV)
     rgba, dist, hits, vis = raster.trace(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
     assert raster.stats()["num_intersections"] == 0
     assert float(rgba.abs().max()) == 0 and float(hits.abs().max()) == 0 and float(vis.abs().max()) == 0
+    assert float((dist - 1e6).abs().max()) == 0
     dg, sg = raster.trace_bwd(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1],
                               rgba, torch.ones_like(rgba), dist, torch.zeros_like(dist))
     assert float(dg.abs().max()) == 0 and float(sg.abs().max()) == 0
