@@ -53,7 +53,7 @@ class GutStats(C.Structure):
 
 
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
-           "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_last_error", "gut_abi_version")
+           "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version")
 
 _lib = None
 
@@ -84,6 +84,7 @@ def load():
     lib.gut_debug_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.gut_debug_copy.argtypes = [vp, i32, vp, C.c_size_t]
     lib.gut_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.gut_kernel_times_mean.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
     _lib = lib

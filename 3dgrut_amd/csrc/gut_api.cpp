@@ -136,7 +136,16 @@ struct gut_context {
     // timers
     std::deque<EventPair> fwd_timers, bwd_timers;
     float last_fwd_ms = -1.f, last_bwd_ms = -1.f;
-    hipEvent_t kev[16] = {};  // per-kernel boundaries of the last call
+    // per-kernel event boundaries: a ring of sets so that bench.py can average over its whole timed region
+    static constexpr int kRing = 64;
+    struct KevSet {
+        hipEvent_t e[12] = {};
+        bool fwd = false, bwd = false;
+    };
+    KevSet ring[kRing];
+    int ring_cur = 0;    // set used by the most recent trace()
+    int ring_count = 0;  // sets recorded since the last gut_kernel_times_mean
+    hipEvent_t* kev = ring[0].e;
     bool kev_fwd_valid = false, kev_bwd_valid = false;
 };
 
@@ -287,8 +296,10 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
         delete h;
         return fail("gut_create: allocation failed: %s", hipGetErrorString(e));
     }
-    for (auto& ev : h->kev)
-        if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+    if (cfg->enable_kernel_timings)
+        for (auto& set : h->ring)
+            for (auto& ev : set.e)
+                if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
     *out = h;
     return 0;
 }
@@ -304,8 +315,9 @@ void gut_destroy(gut_handle h) {
     if (h->host_count) (void)hipHostFree(h->host_count);
     (void)drain_timers(h->fwd_timers);
     (void)drain_timers(h->bwd_timers);
-    for (auto& ev : h->kev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto& set : h->ring)
+        for (auto& ev : set.e)
+            if (ev) (void)hipEventDestroy(ev);
     delete h;
 }
 
@@ -346,6 +358,12 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     const bool timing = h->cfg.enable_kernel_timings != 0;
     EventPair* total = timing ? arm_timer(h->fwd_timers, s) : nullptr;
     h->kev_fwd_valid = false;
+    if (timing) {
+        h->ring_cur = (h->ring_cur + 1) % gut_context::kRing;
+        h->kev = h->ring[h->ring_cur].e;
+        h->ring[h->ring_cur].fwd = false;
+        h->ring[h->ring_cur].bwd = false;
+    }
     auto mark = [&](int i) {
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
     };
@@ -399,6 +417,10 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
         total->armed = true;
     }
     h->kev_fwd_valid = timing;
+    if (timing) {
+        h->ring[h->ring_cur].fwd = true;
+        if (h->ring_count < gut_context::kRing) h->ring_count++;
+    }
     h->have_forward = true;
     h->fwd_stream = s;
     h->n = n;
@@ -468,6 +490,7 @@ int gut_trace_bwd(gut_handle h, void* stream_, uint32_t frame_number, int32_t nu
         total->armed = true;
     }
     h->kev_bwd_valid = timing;
+    if (timing) h->ring[h->ring_cur].bwd = true;
     h->have_backward = true;
     return 0;
 }
@@ -506,6 +529,32 @@ int gut_kernel_times(gut_handle h, float* ms8) {
         ms8[6] = span(9, 10);   // render backward
         ms8[7] = span(10, 11);  // project backward
     }
+    return 0;
+}
+
+int gut_kernel_times_mean(gut_handle h, float* ms8, int32_t* count) {
+    if (!h || !ms8) return fail("gut_kernel_times_mean: null argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->cfg.enable_kernel_timings) return fail("gut_kernel_times_mean: enable_kernel_timings is off");
+    double sum[GUT_NUM_KERNEL_TIMERS] = {};
+    int cnt[GUT_NUM_KERNEL_TIMERS] = {};
+    static const int kA[GUT_NUM_KERNEL_TIMERS] = {0, 1, 2, 3, 4, 5, 9, 10};
+    static const int kB[GUT_NUM_KERNEL_TIMERS] = {1, 2, 3, 4, 5, 6, 10, 11};
+    for (int k = 0; k < h->ring_count; ++k) {
+        const auto& set = h->ring[(h->ring_cur - k + 2 * gut_context::kRing) % gut_context::kRing];
+        for (int i = 0; i < GUT_NUM_KERNEL_TIMERS; ++i) {
+            const bool ok = i < 6 ? set.fwd : set.bwd;
+            if (!ok || !set.e[kA[i]] || !set.e[kB[i]]) continue;
+            float ms = 0.f;
+            if (hipEventSynchronize(set.e[kB[i]]) == hipSuccess && hipEventElapsedTime(&ms, set.e[kA[i]], set.e[kB[i]]) == hipSuccess) {
+                sum[i] += ms;
+                cnt[i]++;
+            }
+        }
+    }
+    for (int i = 0; i < GUT_NUM_KERNEL_TIMERS; ++i) ms8[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : -1.f;
+    if (count) *count = h->ring_count;
+    h->ring_count = 0;
     return 0;
 }
 

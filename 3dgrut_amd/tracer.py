@@ -252,6 +252,12 @@ class SplatRaster:
         _capi.check(self._lib.gut_kernel_times(self._handle, arr), "kernel_times")
         return dict(zip(_capi.KERNEL_TIMER_NAMES, [float(v) for v in arr]))
 
+    def kernel_times_mean(self):
+        arr = (C.c_float * _capi.GUT_NUM_KERNEL_TIMERS)()
+        cnt = C.c_int32(0)
+        _capi.check(self._lib.gut_kernel_times_mean(self._handle, arr, C.byref(cnt)), "kernel_times_mean")
+        return dict(zip(_capi.KERNEL_TIMER_NAMES, [float(v) for v in arr])), int(cnt.value)
+
     def debug_buffer(self, name, device=None):
         """Copy of an intermediate buffer as a torch tensor (parity tests)."""
         ptr, nbytes = C.c_void_p(), C.c_size_t()

@@ -1,0 +1,95 @@
+"""Train-step harness for the 3DGUT path: the call sequence of the reference's hot loop
+(threedgrut/trainer.py:705-778) with nothing but the renderer swapped —
+
+    outputs = model(gpu_batch, train=True)      -> Tracer.render (HIP)
+    loss    = 0.8 * L1 + 0.2 * (1 - SSIM)       (configs/base_gs.yaml:111-119, trainer.py:425-450)
+    loss.backward()                              -> Tracer._Autograd.backward (HIP)
+    [data parallel: all-reduce of the Gaussian gradients over RCCL]
+    optimizer.step(); optimizer.zero_grad()     (Adam, eps 1e-15, reference learning rates)
+
+The reference's SSIM is the external CUDA-only `fused_ssim` package (model/losses.py:17-33,
+requirements.txt:23); here it is a separable 11-tap Gaussian-window SSIM written with torch convolutions
+(`padding="valid"` like the reference call) — a stand-in until the HIP SSIM kernel of SURVEY §8f-N1 lands.
+Per-view data parallelism: one process per GPU, full replica, rank r renders view
+step*world+r, gradients are summed with an RCCL all-reduce and divided by the world size.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+def _gauss_window(size=11, sigma=1.5, device="cpu", dtype=torch.float32):
+    x = torch.arange(size, dtype=dtype, device=device) - (size - 1) / 2
+    g = torch.exp(-(x * x) / (2 * sigma * sigma))
+    return g / g.sum()
+
+
+def ssim(img1, img2, window=None):
+    """img: [B,3,H,W] in [0,1]; separable Gaussian window, valid padding; returns the mean SSIM."""
+    c = img1.shape[1]
+    if window is None:
+        window = _gauss_window(device=img1.device, dtype=img1.dtype)
+    wh = window.view(1, 1, 1, -1).expand(c, 1, 1, -1)
+    wv = window.view(1, 1, -1, 1).expand(c, 1, -1, 1)
+
+    def blur(x):
+        return F.conv2d(F.conv2d(x, wh, groups=c), wv, groups=c)
+
+    mu1, mu2 = blur(img1), blur(img2)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = blur(img1 * img1) - mu1_sq
+    s2 = blur(img2 * img2) - mu2_sq
+    s12 = blur(img1 * img2) - mu12
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu12 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
+    return m.mean()
+
+
+def photometric_loss(pred_rgb, gt_rgb, lambda_l1=0.8, lambda_ssim=0.2, window=None):
+    """pred/gt: [B,H,W,3].  0.8*L1 + 0.2*(1-SSIM) (trainer.py:449)."""
+    l1 = (pred_rgb - gt_rgb).abs().mean()
+    s = ssim(pred_rgb.permute(0, 3, 1, 2), gt_rgb.permute(0, 3, 1, 2), window)
+    return lambda_l1 * l1 + lambda_ssim * (1.0 - s)
+
+
+class TrainStep:
+    def __init__(self, model, tracer, scene_extent=1.0, world_size=1, fused_adam=True):
+        self.model = model
+        self.tracer = tracer
+        self.world_size = world_size
+        kw = dict(eps=1e-15)
+        if fused_adam and next(model.parameters()).is_cuda:
+            kw["fused"] = True
+        self.optimizer = torch.optim.Adam(model.param_groups(scene_extent), **kw)
+        self.window = _gauss_window(device=next(model.parameters()).device)
+        self.step_id = 0
+
+    def render(self, batch, train=True):
+        return self.tracer.render(self.model, batch, train=train, frame_id=self.step_id)
+
+    def step(self, batch):
+        out = self.render(batch, train=True)
+        loss = photometric_loss(out["pred_rgb"], batch.rgb_gt, window=self.window)
+        loss.backward()
+        if self.world_size > 1:
+            self.allreduce_gradients()
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        self.step_id += 1
+        return loss, out
+
+    def allreduce_gradients(self):
+        """SUM over ranks then divide: the loss of a step is the mean over the views of all ranks.
+        One collective per parameter tensor (6 large messages; SH is 81 % of the bytes), issued
+        back-to-back and awaited together so RCCL can pipeline them over the xGMI links."""
+        works = []
+        for p in self.model.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        inv = 1.0 / self.world_size
+        torch._foreach_mul_([p.grad for p in self.model.parameters()], inv)

@@ -156,6 +156,9 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * enable_kernel_timings; synchronises. */
 #define GUT_NUM_KERNEL_TIMERS 8
 int gut_kernel_times(gut_handle h, float* ms8);
+/* mean per-kernel time over the (at most 64 most recent) trace/trace_bwd calls since the previous call of this
+ * function; *count = number of forward calls averaged.  Synchronises. */
+int gut_kernel_times_mean(gut_handle h, float* ms8, int32_t* count);
 
 const char* gut_last_error(void);
 int gut_abi_version(void);
