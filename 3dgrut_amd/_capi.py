@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgut_hip.so")
+LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  # override: dev experiments only
 
 GUT_ABI_VERSION = 1
 GUT_NUM_KERNEL_TIMERS = 8

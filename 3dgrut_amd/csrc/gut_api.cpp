@@ -121,7 +121,7 @@ struct gut_context {
     // per-M scratch
     DevBuf keys_unsorted, keys_sorted, ids_unsorted, ids_sorted, sort_temp;
     // per-T
-    DevBuf ranges;
+    DevBuf ranges, trav_fwd, trav_bwd;  // per-tile traversal depths (statistics)
     DevBuf counters;
     uint32_t* host_count = nullptr;  // pinned
 
@@ -310,7 +310,7 @@ void gut_destroy(gut_handle h) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
-                      &h->sort_temp, &h->ranges, &h->counters};
+                      &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->counters};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     (void)drain_timers(h->fwd_timers);
@@ -353,6 +353,8 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     HIP_TRY(h->depth.ensure(sizeof(float) * (size_t)n));
     HIP_TRY(h->feat.ensure(sizeof(float) * 3 * (size_t)n));
     HIP_TRY(h->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)tiles));
+    HIP_TRY(h->trav_fwd.ensure(sizeof(uint32_t) * (size_t)tiles));
+    HIP_TRY(h->trav_bwd.ensure(sizeof(uint32_t) * (size_t)tiles));
     if (n) HIP_TRY(h->scan_temp.ensure(gut::scan_temp_bytes(n)));
 
     const bool timing = h->cfg.enable_kernel_timings != 0;
@@ -368,7 +370,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
     };
 
-    HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(gut::Counters), s));
+    HIP_TRY(hipMemsetAsync(h->trav_bwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
     mark(0);
     gut::launch_project(s, v, h->consts, n, num_active_features, d_particle_density, d_particle_radiance,
                         h->tiles_count.as<uint32_t>(), h->proj_pos.as<float>(), h->conic_opacity.as<float>(),
@@ -409,7 +411,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     // running the compositor over empty ranges writes exactly those values
     gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
                        h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, d_ray_radiance_density, d_ray_hit_distance,
-                       d_ray_hit_count, h->counters.as<gut::Counters>());
+                       d_ray_hit_count, h->trav_fwd.as<uint32_t>());
     mark(6);
     HIP_TRY(hipGetLastError());
     if (total) {
@@ -479,7 +481,7 @@ int gut_trace_bwd(gut_handle h, void* stream_, uint32_t frame_number, int32_t nu
         gut::launch_render_bwd(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
                                h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_ray_radiance_density,
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
-                               h->counters.as<gut::Counters>());
+                               h->trav_bwd.as<uint32_t>());
     mark(10);
     gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
                             h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad);
@@ -564,9 +566,12 @@ int gut_get_stats(gut_handle h, GutStats* out) {
     memset(out, 0, sizeof(*out));
     if (!h->have_forward) return fail("gut_get_stats: no forward yet");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->fwd_stream));
+    HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(gut::Counters), h->fwd_stream));
+    gut::launch_stats_reduce(h->fwd_stream, h->n, h->tiles_count.as<uint32_t>(), (uint32_t)h->tiles, h->trav_fwd.as<uint32_t>(),
+                             h->trav_bwd.as<uint32_t>(), h->counters.as<gut::Counters>());
     gut::Counters c;
-    HIP_TRY(hipMemcpy(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->fwd_stream));
+    HIP_TRY(hipStreamSynchronize(h->fwd_stream));
     out->num_particles = h->n;
     out->num_visible = c.visible;
     out->num_intersections = h->m;

@@ -66,11 +66,13 @@ void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_d
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                    const uint32_t* sorted_ids, uint32_t num_intersections, float* rgba, float* dist, float* hits,
-                   Counters* counters);
+                   uint32_t* tile_traversed);
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, Counters* counters);
+                       float* grad16, uint32_t* tile_traversed);
+void launch_stats_reduce(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint32_t t, const uint32_t* trav_fwd,
+                         const uint32_t* trav_bwd, Counters* out);
 
 // scan / sort (rocPRIM device-wide primitives; temp storage owned by the caller)
 size_t scan_temp_bytes(uint32_t n);

@@ -70,13 +70,22 @@ __device__ __forceinline__ bool within_resolution(float rx, float ry, float tol,
 }
 
 // OpenCV pinhole with rational radial / tangential / thin-prism distortion (cameraProjections.cuh:57-103)
-__device__ bool project_pinhole(const ViewParams& v, float px, float py, float pz, float tol, float& ox, float& oy) {
+template <bool kDistorted>
+__device__ __forceinline__ bool project_pinhole(const ViewParams& v, float px, float py, float pz, float tol, float& ox,
+                                                float& oy) {
     if (pz <= 0.0f) {
         ox = 0.0f;
         oy = 0.0f;
         return false;
     }
-    const float un = px / pz, vn = py / pz;
+    // xy / z as multiplication by one IEEE reciprocal (numerics contract, mirrored by the oracle)
+    const float rz = 1.0f / pz;
+    const float un = px * rz, vn = py * rz;
+    if (!kDistorted) {  // all distortion coefficients are zero: icd == 1, delta == 0 exactly
+        ox = un * v.focal_length[0] + v.principal_point[0];
+        oy = vn * v.focal_length[1] + v.principal_point[1];
+        return within_resolution((float)v.width, (float)v.height, tol, ox, oy);
+    }
     const float u2 = un * un, v2 = vn * vn;
     const float r2 = u2 + v2;
     const float a1 = 2.0f * un * vn;
@@ -103,7 +112,7 @@ __device__ bool project_pinhole(const ViewParams& v, float px, float py, float p
 }
 
 // OpenCV fisheye, theta clamped to max_angle (cameraProjections.cuh:105-128)
-__device__ bool project_fisheye(const ViewParams& v, float px, float py, float pz, float tol, float& ox, float& oy) {
+__device__ __forceinline__ bool project_fisheye(const ViewParams& v, float px, float py, float pz, float tol, float& ox, float& oy) {
     const float eps = 1.1920929e-07f;
     float rho = sqrtf(px * px + py * py);
     rho = rho > eps ? rho : eps;
@@ -120,13 +129,17 @@ __device__ bool project_fisheye(const ViewParams& v, float px, float py, float p
     return (theta < v.max_angle) && within_resolution((float)v.width, (float)v.height, tol, ox, oy);
 }
 
+// kVariant: 0 = pinhole without distortion, 1 = pinhole with distortion, 2 = fisheye (compile-time specialisation of
+// the reference's run-time camera-model switch, cameraProjections.cuh:130-144)
+template <int kVariant>
 __device__ __forceinline__ int project_world(const ViewParams& v, float wx, float wy, float wz, float tol, float& ox,
                                              float& oy) {
     const Affine& a = v.w2s_start;
     const float cx = a.r[0][0] * wx + a.r[0][1] * wy + a.r[0][2] * wz + a.t[0];
     const float cy = a.r[1][0] * wx + a.r[1][1] * wy + a.r[1][2] * wz + a.t[1];
     const float cz = a.r[2][0] * wx + a.r[2][1] * wy + a.r[2][2] * wz + a.t[2];
-    if (v.model == GUT_CAMERA_OPENCV_PINHOLE) return project_pinhole(v, cx, cy, cz, tol, ox, oy) ? 1 : 0;
+    if (kVariant == 0) return project_pinhole<false>(v, cx, cy, cz, tol, ox, oy) ? 1 : 0;
+    if (kVariant == 1) return project_pinhole<true>(v, cx, cy, cz, tol, ox, oy) ? 1 : 0;
     return project_fisheye(v, cx, cy, cz, tol, ox, oy) ? 1 : 0;
 }
 
@@ -217,7 +230,25 @@ __device__ float tile_min_power(float tx, float ty, float c0, float c1, float c2
 
 // ---------------------------------------------------------------------------------------------------
 // K1
+//
+// MI355X shape: one lane per Gaussian, 4 waves per workgroup.  Two things keep this kernel on the HBM
+// roofline instead of the L2 one:
+//   * tile counting: footprints of up to kSerialTiles tiles are walked by their own lane; larger ones are
+//     handed to the whole wave one at a time (64 tiles tested per step, counted with ballot+popcount), so a
+//     screen-filling splat costs area/64 steps instead of stalling 63 idle lanes for `area` steps;
+//   * SH coefficients: the 64 Gaussians of a wave own one contiguous 12 KiB block of the [N,48] tensor, which
+//     the wave streams into LDS with fully coalesced 16-byte loads (row stride 49 dwords -> the later
+//     row-per-lane reads are bank-conflict-free) instead of 12 strided float4 loads per lane that touch 64
+//     cache lines each.
+// Neither changes any arithmetic: the per-tile test and the SH dot products are evaluated exactly as before.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kSerialTiles = 12;
+constexpr int kShRow = 49;  // padded LDS row stride (dwords)
+
+__device__ __forceinline__ float bcast(float v, int src_lane) { return __shfl(v, src_lane); }
+__device__ __forceinline__ int bcast(int v, int src_lane) { return __shfl(v, src_lane); }
+
+template <int kVariant>
 __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, RenderConsts c, uint32_t n, int sh_degree,
                                                             const float4* __restrict__ density12,
                                                             const float* __restrict__ sph48,
@@ -225,37 +256,42 @@ __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, Rende
                                                             float4* __restrict__ conic_opacity, float2* __restrict__ extent,
                                                             float* __restrict__ depth, float* __restrict__ feat,
                                                             float* __restrict__ visibility, Counters* __restrict__ counters) {
+    __shared__ float sh_lds[(kBlock / 64) * 32 * kShRow];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = (int)(threadIdx.x >> 6);
     uint32_t cnt = 0;
-    bool conic_ok = false;
+    bool conic_ok = false, ok = false;
     float cx = 0.f, cy = 0.f, con0 = 0.f, con1 = 0.f, con2 = 0.f, con3 = 0.f, ex = 0.f, ey = 0.f, zkey = 0.f;
-    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, max_power = 0.f, zcam = 0.f;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t wave_first = blockIdx.x * kBlock + (uint32_t)wave * 64u;  // first Gaussian of this wave
+    const uint32_t rows_here = wave_first < n ? min(64u, n - wave_first) : 0u;
     if (i < n) {
-        const float4 a = density12[3 * (size_t)i + 0];  // pos.xyz, density
-        const float4 b = density12[3 * (size_t)i + 1];  // quat wxyz
-        const float4 d = density12[3 * (size_t)i + 2];  // scale.xyz, pad
+        a = density12[3 * (size_t)i + 0];                // pos.xyz, density
+        const float4 b = density12[3 * (size_t)i + 1];   // quat wxyz
+        const float4 d = density12[3 * (size_t)i + 2];   // scale.xyz, pad
         const float opacity_in = a.w;
         const Affine& m = v.w2s_mid;
-        const float zcam = a.x * m.r[2][0] + a.y * m.r[2][1] + a.z * m.r[2][2] + m.t[2];
-        bool ok = !(opacity_in < c.alpha_threshold) && !(zcam < c.min_sensor_z);
-        float max_power = 0.f;
+        zcam = a.x * m.r[2][0] + a.y * m.r[2][1] + a.z * m.r[2][2] + m.t[2];
+        ok = !(opacity_in < c.alpha_threshold) && !(zcam < c.min_sensor_z);
         if (ok) {
             // unscented transform: 7 sigma points through the full camera model (gutProjector.cuh:118-215)
             float rows[3][3];
             quat_rows(b.x, b.y, b.z, b.w, rows);
             const float scl[3] = {d.x, d.y, d.z};
             float sx[7], sy[7];
-            int nvalid = project_world(v, a.x, a.y, a.z, c.ut_margin, sx[0], sy[0]);
+            int nvalid = project_world<kVariant>(v, a.x, a.y, a.z, c.ut_margin, sx[0], sy[0]);
             cx = sx[0] * c.ut_w0_mean;
             cy = sy[0] * c.ut_w0_mean;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float kk = c.ut_delta * scl[k];
                 const float dx = kk * rows[k][0], dy = kk * rows[k][1], dz = kk * rows[k][2];
-                nvalid += project_world(v, a.x + dx, a.y + dy, a.z + dz, c.ut_margin, sx[k + 1], sy[k + 1]);
+                nvalid += project_world<kVariant>(v, a.x + dx, a.y + dy, a.z + dz, c.ut_margin, sx[k + 1], sy[k + 1]);
                 cx += c.ut_wi * sx[k + 1];
                 cy += c.ut_wi * sy[k + 1];
-                nvalid += project_world(v, a.x - dx, a.y - dy, a.z - dz, c.ut_margin, sx[k + 4], sy[k + 4]);
+                nvalid += project_world<kVariant>(v, a.x - dx, a.y - dy, a.z - dz, c.ut_margin, sx[k + 4], sy[k + 4]);
                 cx += c.ut_wi * sx[k + 4];
                 cy += c.ut_wi * sy[k + 4];
             }
@@ -280,11 +316,12 @@ __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, Rende
                 const float ddet = dcx * dcz - dcy * dcy;
                 ok = !(ddet == 0.0f);
                 if (ok) {
-                    con0 = dcz / ddet;
-                    con1 = -dcy / ddet;
-                    con2 = dcx / ddet;
+                    const float inv_det = 1.0f / ddet;
+                    con0 = dcz * inv_det;
+                    con1 = -dcy * inv_det;
+                    con2 = dcx * inv_det;
                     const float cdet = cov0 * cov2 - cov1 * cov1;
-                    const float ratio = cdet / ddet;
+                    const float ratio = cdet * inv_det;
                     const float conv = sqrtf(ratio > 0.000025f ? ratio : 0.000025f);
                     con3 = opacity_in * conv;
                     ok = !(con3 < c.alpha_threshold);
@@ -313,42 +350,101 @@ __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, Rende
                 }
             }
         }
-        if (ok) {
-            const TileBox bb = tile_bbox(v.grid_x, v.grid_y, cx, cy, ex, ey);
-            if (c.tile_culling) {
-                for (int y = bb.y0; y < bb.y1; ++y)
-                    for (int x = bb.x0; x < bb.x1; ++x)
-                        if (tile_min_power((float)x, (float)y, con0, con1, con2, cx, cy) < max_power) cnt++;
-            } else {
-                cnt = (uint32_t)((bb.x1 - bb.x0) * (bb.y1 - bb.y0));
-            }
+    }
+
+    // ---- tile counting ----
+    TileBox bb = {0, 0, 0, 0};
+    int area = 0;
+    if (ok) {
+        bb = tile_bbox(v.grid_x, v.grid_y, cx, cy, ex, ey);
+        area = (bb.x1 - bb.x0) * (bb.y1 - bb.y0);
+    }
+    if (!c.tile_culling) {
+        cnt = (uint32_t)area;
+    } else {
+        if (area > 0 && area <= kSerialTiles) {
+            for (int y = bb.y0; y < bb.y1; ++y)
+                for (int x = bb.x0; x < bb.x1; ++x)
+                    if (tile_min_power((float)x, (float)y, con0, con1, con2, cx, cy) < max_power) cnt++;
         }
-        if (cnt != 0) {
-            // view-dependent colour evaluated once per Gaussian along (mean - sensor position), unclamped, +0.5
-            const float rx = a.x - v.s2w.t[0], ry = a.y - v.s2w.t[1], rz = a.z - v.s2w.t[2];
-            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
-            float Y[16];
-            sh_basis(sh_degree, rx / dist, ry / dist, rz / dist, Y);
-            const int ncoef = (sh_degree + 1) * (sh_degree + 1);
-            const float4* sh4 = reinterpret_cast<const float4*>(sph48 + (size_t)i * 48);
-            float sh[48];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const float4 q = sh4[k];
-                sh[4 * k + 0] = q.x; sh[4 * k + 1] = q.y; sh[4 * k + 2] = q.z; sh[4 * k + 3] = q.w;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < ncoef) {
-                    f0 += Y[k] * sh[3 * k + 0];
-                    f1 += Y[k] * sh[3 * k + 1];
-                    f2 += Y[k] * sh[3 * k + 2];
+        unsigned long long todo = __ballot(area > kSerialTiles);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int jx0 = bcast(bb.x0, j), jy0 = bcast(bb.y0, j), jw = bcast(bb.x1 - bb.x0, j), jarea = bcast(area, j);
+            const float j0 = bcast(con0, j), j1 = bcast(con1, j), j2 = bcast(con2, j), jcx = bcast(cx, j), jcy = bcast(cy, j),
+                        jmp = bcast(max_power, j);
+            uint32_t total = 0;
+            for (int base = 0; base < jarea; base += 64) {
+                const int t = base + lane;
+                bool pass = false;
+                if (t < jarea) {
+                    const int ty = t / jw;
+                    const int tx = t - ty * jw;
+                    pass = tile_min_power((float)(jx0 + tx), (float)(jy0 + ty), j0, j1, j2, jcx, jcy) < jmp;
                 }
-            f0 += 0.5f; f1 += 0.5f; f2 += 0.5f;
-            zkey = c.global_z_order ? zcam : dist;
-        } else {
-            cx = cy = con0 = con1 = con2 = con3 = ex = ey = 0.0f;
+                total += (uint32_t)__popcll(__ballot(pass));
+            }
+            if (lane == j) cnt = total;
         }
+    }
+
+    // ---- view-dependent colour ----
+    // The 64 Gaussians of a wave own one contiguous 12 KiB block of the [N,48] SH tensor.  It is read with fully
+    // coalesced 16-byte loads and transposed through a wave-private LDS region (32 rows x 49 dwords, two passes;
+    // no workgroup barrier: LDS operations of one wave execute in order) so that each lane ends up with its own row.
+    const bool vis = cnt != 0;
+    if (__ballot(vis) != 0ull) {
+        float* wl = sh_lds + wave * 32 * kShRow;
+        const float4* src = reinterpret_cast<const float4*>(sph48 + (size_t)wave_first * 48);
+        float Y[16];
+        float inv_dist = 0.f, dist = 0.f;
+        if (vis) {
+            const float rx = a.x - v.s2w.t[0], ry = a.y - v.s2w.t[1], rz = a.z - v.s2w.t[2];
+            dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            inv_dist = 1.0f / dist;
+            sh_basis(sh_degree, rx * inv_dist, ry * inv_dist, rz * inv_dist, Y);
+        }
+        const int ncoef = (sh_degree + 1) * (sh_degree + 1);
+        float4 shq[12];
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const uint32_t q = (uint32_t)it * 64u + (uint32_t)lane;  // float4 index inside the 12 KiB block
+            shq[it] = (q < rows_here * 12u) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int it6 = 0; it6 < 6; ++it6) {
+                const uint32_t q = (uint32_t)it6 * 64u + (uint32_t)lane;  // float4 index inside this half (32 rows)
+                const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
+                float* dst = wl + row * kShRow + col;
+                const float4 val = shq[half * 6 + it6];
+                dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (vis && (lane >> 5) == half) {
+                const float* sh = wl + (lane & 31) * kShRow;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < ncoef) {
+                        f0 += Y[k] * sh[3 * k + 0];
+                        f1 += Y[k] * sh[3 * k + 1];
+                        f2 += Y[k] * sh[3 * k + 2];
+                    }
+                f0 += 0.5f; f1 += 0.5f; f2 += 0.5f;
+                zkey = c.global_z_order ? zcam : dist;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+
+    if (i < n) {
+        if (!vis) cx = cy = con0 = con1 = con2 = con3 = ex = ey = 0.0f;
         tiles_count[i] = cnt;
         proj_pos[i] = make_float2(cx, cy);
         conic_opacity[i] = make_float4(con0, con1, con2, con3);
@@ -361,12 +457,14 @@ __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, Rende
         // patterns in a float tensor, and validProjection && validConic instead of validConic alone.
         visibility[i] = conic_ok ? 1.0f : 0.0f;
     }
-    const unsigned long long vis_mask = __ballot(cnt != 0);
-    if ((threadIdx.x & 63) == 0 && vis_mask) atomicAdd(&counters->visible, (unsigned long long)__popcll(vis_mask));
+    // NB: no global "visible" counter here — 94 k same-address atomics cost ~1 ms at N = 6 M (they serialise at the
+    // memory side).  V is counted on demand from tiles_count (k_stats_reduce, gut_get_stats).
+    (void)counters;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3
+// K3: emit (tile|depth, id) pairs at tilesOffset[i-1]...  Same serial/cooperative split as K1; the cooperative
+// path writes in the same row-major tile order (ballot prefix), so the unsorted buffers are identical.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderConsts c, uint32_t n,
                                                         const uint32_t* __restrict__ offset,
@@ -375,17 +473,40 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
                                                         const float2* __restrict__ extent, const float* __restrict__ depth,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ ids) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float2 e = extent[i];
-    if (e.x <= 1e-06f) return;
-    const uint32_t dkey = f2u(depth[i]);
-    uint32_t off = (i == 0) ? 0u : offset[i - 1];
-    const uint32_t max_off = offset[i];
-    const float2 p = proj_pos[i];
-    const TileBox bb = tile_bbox(v.grid_x, v.grid_y, p.x, p.y, e.x, e.y);
-    if (c.tile_culling) {
-        const float4 con = conic_opacity[i];
-        const float max_power = det_logf(con.w / c.alpha_threshold);
+    const int lane = (int)(threadIdx.x & 63);
+    bool active = false;
+    float2 e = make_float2(0.f, 0.f), p = make_float2(0.f, 0.f);
+    float4 con = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t dkey = 0, off = 0, max_off = 0;
+    float max_power = 0.f;
+    TileBox bb = {0, 0, 0, 0};
+    int area = 0;
+    if (i < n) {
+        e = extent[i];
+        active = !(e.x <= 1e-06f);
+    }
+    if (active) {
+        dkey = f2u(depth[i]);
+        off = (i == 0) ? 0u : offset[i - 1];
+        max_off = offset[i];
+        p = proj_pos[i];
+        bb = tile_bbox(v.grid_x, v.grid_y, p.x, p.y, e.x, e.y);
+        area = (bb.x1 - bb.x0) * (bb.y1 - bb.y0);
+        con = conic_opacity[i];
+        if (c.tile_culling) max_power = det_logf(con.w / c.alpha_threshold);
+    }
+    if (!c.tile_culling) {
+        if (active)
+            for (int y = bb.y0; y < bb.y1; ++y)
+                for (int x = bb.x0; x < bb.x1; ++x) {
+                    keys[off] = ((uint64_t)(uint32_t)(y * v.grid_x + x) << 32) | dkey;
+                    ids[off] = i;
+                    off++;
+                }
+        return;
+    }
+    const bool serial = active && area <= kSerialTiles;
+    if (serial) {
         for (int y = bb.y0; (y < bb.y1) && (off < max_off); ++y)
             for (int x = bb.x0; (x < bb.x1) && (off < max_off); ++x)
                 if (tile_min_power((float)x, (float)y, con.x, con.y, con.z, p.x, p.y) < max_power) {
@@ -393,18 +514,41 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
                     ids[off] = i;
                     off++;
                 }
+    }
+    unsigned long long todo = __ballot(active && area > kSerialTiles);
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int jx0 = bcast(bb.x0, j), jy0 = bcast(bb.y0, j), jw = bcast(bb.x1 - bb.x0, j), jarea = bcast(area, j);
+        const float j0 = bcast(con.x, j), j1 = bcast(con.y, j), j2 = bcast(con.z, j), jcx = bcast(p.x, j), jcy = bcast(p.y, j),
+                    jmp = bcast(max_power, j);
+        const uint32_t jdkey = (uint32_t)bcast((int)dkey, j), jmax = (uint32_t)bcast((int)max_off, j);
+        const uint32_t jid = blockIdx.x * kBlock + (threadIdx.x & ~63u) + (uint32_t)j;
+        uint32_t joff = (uint32_t)bcast((int)off, j);
+        for (int base = 0; base < jarea; base += 64) {
+            const int t = base + lane;
+            bool pass = false;
+            int tx = 0, ty = 0;
+            if (t < jarea) {
+                ty = t / jw;
+                tx = t - ty * jw;
+                pass = tile_min_power((float)(jx0 + tx), (float)(jy0 + ty), j0, j1, j2, jcx, jcy) < jmp;
+            }
+            const unsigned long long mask = __ballot(pass);
+            const uint32_t my = joff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (pass && my < jmax) {
+                keys[my] = ((uint64_t)(uint32_t)((jy0 + ty) * v.grid_x + (jx0 + tx)) << 32) | jdkey;
+                ids[my] = jid;
+            }
+            joff += (uint32_t)__popcll(mask);
+        }
+        if (lane == j) off = joff < jmax ? joff : jmax;
+    }
+    if (active)
         for (; off < max_off; ++off) {  // pad (cannot happen while K1 and K3 evaluate the same test; kept for parity)
             keys[off] = ((uint64_t)kInvalid << 32) | f2u(3.4028235e+38f);
             ids[off] = kInvalid;
         }
-    } else {
-        for (int y = bb.y0; y < bb.y1; ++y)
-            for (int x = bb.x0; x < bb.x1; ++x) {
-                keys[off] = ((uint64_t)(uint32_t)(y * v.grid_x + x) << 32) | dkey;
-                ids[off] = i;
-                off++;
-            }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -455,8 +599,9 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
         const float4 a = density12[3 * (size_t)i];
         const float rx = a.x - v.s2w.t[0], ry = a.y - v.s2w.t[1], rz = a.z - v.s2w.t[2];
         const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float inv_dist = 1.0f / dist;
         float Y[16];
-        sh_basis(sh_degree, rx / dist, ry / dist, rz / dist, Y);
+        sh_basis(sh_degree, rx * inv_dist, ry * inv_dist, rz * inv_dist, Y);
         const int ncoef = (sh_degree + 1) * (sh_degree + 1);
         const float m0 = feat[3 * (size_t)i + 0] > 0.0f ? dr : 0.0f;
         const float m1 = feat[3 * (size_t)i + 1] > 0.0f ? dg : 0.0f;
@@ -478,6 +623,35 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
 }
 
 // ---------------------------------------------------------------------------------------------------
+// statistics on demand (gut_get_stats): V = #{tiles_count > 0}, E_f / E_b = sums of the per-tile traversal depths
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_stats_reduce(uint32_t n, const uint32_t* __restrict__ tiles_count, uint32_t t,
+                                                        const uint32_t* __restrict__ trav_fwd,
+                                                        const uint32_t* __restrict__ trav_bwd, Counters* __restrict__ out) {
+    unsigned long long v = 0, ef = 0, eb = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) v += tiles_count[i] != 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < t; i += gridDim.x * kBlock) {
+        ef += trav_fwd[i];
+        eb += trav_bwd[i];
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        v += __shfl_xor(v, m);
+        ef += __shfl_xor(ef, m);
+        eb += __shfl_xor(eb, m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (v) atomicAdd(&out->visible, v);
+        if (ef) atomicAdd(&out->traversed_fwd, ef);
+        if (eb) atomicAdd(&out->traversed_bwd, eb);
+    }
+}
+
+void launch_stats_reduce(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint32_t t, const uint32_t* trav_fwd,
+                         const uint32_t* trav_bwd, Counters* out) {
+    hipLaunchKernelGGL(k_stats_reduce, dim3(256), dim3(kBlock), 0, s, n, tiles_count, t, trav_fwd, trav_bwd, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
@@ -487,7 +661,13 @@ void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, u
                     float* conic_opacity, float* extent, float* depth, float* feat, float* visibility,
                     Counters* counters) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_project_on_tiles, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, sh_degree,
+    bool distorted = false;
+    for (float k : v.radial) distorted |= (k != 0.0f);
+    for (float k : v.tangential) distorted |= (k != 0.0f);
+    for (float k : v.thin_prism) distorted |= (k != 0.0f);
+    const int variant = v.model == GUT_CAMERA_OPENCV_FISHEYE ? 2 : (distorted ? 1 : 0);
+    auto kern = variant == 0 ? k_project_on_tiles<0> : (variant == 1 ? k_project_on_tiles<1> : k_project_on_tiles<2>);
+    hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), sph48, tiles_count, reinterpret_cast<float2*>(proj_pos),
                        reinterpret_cast<float4*>(conic_opacity), reinterpret_cast<float2*>(extent), depth, feat, visibility,
                        counters);

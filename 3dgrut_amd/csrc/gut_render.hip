@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                                                   const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
                                                   const uint32_t* __restrict__ sorted_ids, uint32_t num_intersections,
                                                   float4* __restrict__ rgba, float* __restrict__ dist,
-                                                  float* __restrict__ hits, Counters* __restrict__ counters) {
+                                                  float* __restrict__ hits, uint32_t* __restrict__ tile_traversed) {
     __shared__ FwdEntry stage[kBlock];
     __shared__ uint32_t s_deepest;
 
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
     // traversal statistics (E_f of the roofline model): deepest list position any pixel of the tile consumed
     atomicMax(&s_deepest, consumed);
     __syncthreads();
-    if (tid == 0 && s_deepest) atomicAdd(&counters->traversed_fwd, (unsigned long long)s_deepest);
+    if (tid == 0) tile_traversed[tile] = s_deepest;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
                                                            const float4* __restrict__ rgba,
                                                            const float4* __restrict__ rgba_grad,
                                                            const float* __restrict__ dist_grad, float* __restrict__ grad16,
-                                                           Counters* __restrict__ counters) {
+                                                           uint32_t* __restrict__ tile_traversed) {
     __shared__ BwdEntry stage[kBlock];
     __shared__ float acc[kBlock * kGradRow];
     __shared__ uint32_t s_deepest;
@@ -472,30 +472,30 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
 
     atomicMax(&s_deepest, consumed);
     __syncthreads();
-    if (tid == 0 && s_deepest) atomicAdd(&counters->traversed_bwd, (unsigned long long)s_deepest);
+    if (tid == 0) tile_traversed[tile] = s_deepest;
 }
 
 // ---------------------------------------------------------------------------------------------------
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                   uint32_t num_intersections, float* rgba, float* dist, float* hits, Counters* counters) {
+                   uint32_t num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     hipLaunchKernelGGL(k_render, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12), feat,
                        ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, num_intersections,
-                       reinterpret_cast<float4*>(rgba), dist, hits, counters);
+                       reinterpret_cast<float4*>(rgba), dist, hits, tile_traversed);
 }
 
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, Counters* counters) {
+                       float* grad16, uint32_t* tile_traversed) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     hipLaunchKernelGGL(k_render_backward, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
                        reinterpret_cast<const float4*>(rgba), reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
-                       counters);
+                       tile_traversed);
 }
 
 }  // namespace gut

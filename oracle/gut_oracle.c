@@ -205,9 +205,26 @@ static int within_resolution(float rx, float ry, float tol, float px, float py) 
     return (px > -mx) && (py > -my) && (px < rx + mx) && (py < ry + my);
 }
 
+static int pinhole_is_distorted(const OracleCamera* c) {
+    for (int i = 0; i < 6; ++i) if (c->radial[i] != 0.0f) return 1;
+    for (int i = 0; i < 2; ++i) if (c->tangential[i] != 0.0f) return 1;
+    for (int i = 0; i < 4; ++i) if (c->thin_prism[i] != 0.0f) return 1;
+    return 0;
+}
+
 static int project_pinhole(const OracleCamera* c, int W, int H, const float p[3], float tol, float out[2]) {
     if (p[2] <= 0.0f) { out[0] = 0.0f; out[1] = 0.0f; return 0; }
-    const float u = p[0] / p[2], v = p[1] / p[2];
+    /* position.xy()/position.z evaluated as multiplication by one IEEE reciprocal (the reference's
+     * -use_fast_math build lowers its divisions to reciprocal-multiplies too) */
+    const float rz = 1.0f / p[2];
+    const float u = p[0] * rz, v = p[1] * rz;
+    if (!pinhole_is_distorted(c)) {
+        /* all distortion coefficients zero: icD == 1 and delta == 0 exactly, so for finite inputs this is
+         * bit-identical to the general path below; it only differs where r2 overflows (0*inf = NaN there) */
+        out[0] = u * c->focal_length[0] + c->principal_point[0];
+        out[1] = v * c->focal_length[1] + c->principal_point[1];
+        return within_resolution((float)W, (float)H, tol, out[0], out[1]);
+    }
     const float u2 = u * u, v2 = v * v;
     const float r2 = u2 + v2;
     const float a1 = 2.0f * u * v;
@@ -418,9 +435,10 @@ void oracle_project(const OracleParams* prm, const OracleCamera* cam, int W, int
         const float ddet = dcx * dcz - dcy * dcy;
         if (ddet == 0.0f) continue;
         float con[4];
-        con[0] = dcz / ddet; con[1] = -dcy / ddet; con[2] = dcx / ddet;
+        const float inv_det = 1.0f / ddet; /* vec3 / scalar as one reciprocal + multiplies */
+        con[0] = dcz * inv_det; con[1] = -dcy * inv_det; con[2] = dcx * inv_det;
         const float cdet = cov[0] * cov[2] - cov[1] * cov[1];
-        const float ratio = cdet / ddet;
+        const float ratio = cdet * inv_det;
         const float conv = sqrtf(ratio > 0.000025f ? ratio : 0.000025f); /* fmaxf(0.000025, ratio); NaN -> 0.000025 */
         con[3] = opacity_in * conv;
         if (con[3] < prm->alpha_threshold) continue;
@@ -461,7 +479,8 @@ void oracle_project(const OracleParams* prm, const OracleCamera* cam, int W, int
         /* precomputed view-dependent RGB (unclamped), gutProjector.cuh:304-310 */
         const float sr[3] = {pos[0] - ps.cam[0], pos[1] - ps.cam[1], pos[2] - ps.cam[2]};
         const float dist = sqrtf(sr[0] * sr[0] + sr[1] * sr[1] + sr[2] * sr[2]);
-        const float dir[3] = {sr[0] / dist, sr[1] / dist, sr[2] / dist};
+        const float inv_dist = 1.0f / dist;
+        const float dir[3] = {sr[0] * inv_dist, sr[1] * inv_dist, sr[2] * inv_dist};
         float Y[16];
         sh_basis(sh_degree, dir, Y);
         const int ncoef = (sh_degree + 1) * (sh_degree + 1);
@@ -864,7 +883,8 @@ void oracle_project_bwd(const OracleCamera* cam, uint32_t N, int sh_degree,
         const float* g = density12 + (size_t)i * 12;
         const float sr[3] = {g[0] - ps.cam[0], g[1] - ps.cam[1], g[2] - ps.cam[2]};
         const float l = sqrtf(sr[0] * sr[0] + sr[1] * sr[1] + sr[2] * sr[2]);
-        const float dir[3] = {sr[0] / l, sr[1] / l, sr[2] / l};
+        const float inv_l = 1.0f / l;
+        const float dir[3] = {sr[0] * inv_l, sr[1] * inv_l, sr[2] * inv_l};
         float Y[16];
         sh_basis(sh_degree, dir, Y);
         const int ncoef = (sh_degree + 1) * (sh_degree + 1);

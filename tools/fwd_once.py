@@ -1,0 +1,27 @@
+"""Dev tool: a few forward(+backward) renders of the bench scene, for rocprofv3 runs."""
+import importlib, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+gut = importlib.import_module("3dgrut_amd"); scenes = importlib.import_module("3dgrut_amd.scenes")
+cams = importlib.import_module("3dgrut_amd.cameras"); model_mod = importlib.import_module("3dgrut_amd.model")
+dev = "cuda:0"
+W, H, fx = 1237, 822, 1040.0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6_000_000
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+bwd = len(sys.argv) > 3 and sys.argv[3] == "bwd"
+ro, rd = cams.pinhole_rays(W, H, fx, fx); K = cams.pinhole_intrinsics_dict(W, H, fx, fx)
+sc = scenes.scene_outdoor_like(n=n, seed=2)
+model = model_mod.GaussianModel(sc, device=dev)
+tr = gut.Tracer({"render": {"enable_kernel_timings": True}})
+b = gut.Batch(rays_ori=torch.as_tensor(ro, device=dev), rays_dir=torch.as_tensor(rd, device=dev),
+              T_to_world=torch.as_tensor(cams.orbit_c2w(4.5, 7.0, 12.0), device=dev)[None], intrinsics_OpenCVPinholeCameraModelParameters=K)
+for _ in range(iters):
+    if bwd:
+        out = tr.render(model, b, train=True)
+        (out["pred_rgb"].mean() + out["pred_opacity"].mean()).backward()
+        model.zero_grad(set_to_none=True)
+    else:
+        with torch.no_grad():
+            tr.render(model, b)
+torch.cuda.synchronize()
+print(tr.tracer_wrapper.stats(), {k: round(v, 3) for k, v in tr.tracer_wrapper.kernel_times().items()})
