@@ -455,8 +455,9 @@ int gut_trace_bwd(gut_handle h, void* stream_, uint32_t frame_number, int32_t nu
     if (num_particles != h->n || width != h->width || height != h->height || num_active_features != h->sh_degree)
         return fail("gut_trace_bwd: arguments differ from the cached forward (N %u vs %u, %dx%d vs %dx%d)", num_particles, h->n,
                     width, height, h->width, h->height);
-    if (!camera || !d_ray_origin || !d_ray_direction || !d_ray_radiance_density || !d_ray_radiance_density_grad ||
-        !d_ray_hit_distance_grad)
+    // d_ray_hit_distance_grad may be NULL (= all zeros: no loss on pred_dist, the default of the reference's trainer);
+    // the hit-distance gradient terms are then compiled out of the backward kernel
+    if (!camera || !d_ray_origin || !d_ray_direction || !d_ray_radiance_density || !d_ray_radiance_density_grad)
         return fail("gut_trace_bwd: null pointer argument");
     if (num_particles && (!d_particle_density || !d_particle_density_grad || !d_particle_radiance_grad))
         return fail("gut_trace_bwd: null particle buffers");

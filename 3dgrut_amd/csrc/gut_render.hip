@@ -238,31 +238,78 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
 
 // ---------------------------------------------------------------------------------------------------
 // K7 backward
+//
+// Per (pixel, particle) the reference chains dL/d(alpha) through cross/normalise/scale/rotation down to
+// position, scale and quaternion inside the pixel loop (models/gaussianParticles.cuh:516-737) and reduces 11+3
+// floats per pair.  Here the chain is cut at the canonical-space matrix M = diag(1/s) * rotationT:
+//     o = M (ray_o - mu),  u = M ray_d,  d2 = |u x o|^2 / |u|^2
+//     dL/do = 2 g_d2 * o_perp,   dL/du = -2 g_d2 * t * o_perp,   o_perp = o - t u,  t = (u.o)/|u|^2
+// so dL/dM = h (x) m is rank one with h = 2 g_d2 o_perp and m = (ray_o - mu) - t ray_d, and dL/dmu = -M^T h.
+// The pixel loop only accumulates  A += h m^T (9), H += h (3), d(density) (1), d(rgb) (3)  = 16 floats; the
+// conversion of (A, H) into d(position), d(scale), d(quaternion) (matmul_bw_quat, mathUtils.cuh:468-533) runs
+// once per (tile, entry) in a per-chunk epilogue, one entry per lane.  The hit-distance gradient terms of the
+// reference (non-zero only when a loss is put on pred_dist) break the rank-one form; they live in the kDistGrad
+// instantiation, which accumulates the general g_o p^T + g_u d^T and three extra direct scale terms.
+//
+// Reduction over the 64 pixels of a wave: a DPP transpose-reduce (4 exchange steps inside each 16-lane row in
+// which every lane keeps half of its values and adds its partner's copy of them, then two row broadcasts) —
+// ~50 VALU ops for 16 values instead of 16 x 6; lanes 48..63 end up holding one total each and issue ONE
+// ds_add_f32 into the chunk accumulator.  Waves in which no lane hit the entry skip all of it.
 // ---------------------------------------------------------------------------------------------------
-struct BwdEntry {       // 112 bytes
-    float4 mu_sigma;    // mean.xyz, density
-    float4 quat;        // w,x,y,z
-    float4 r0;          // rotationT row 0, 1/s.x
-    float4 r1;          // row 1, 1/s.y
-    float4 r2;          // row 2, 1/s.z
-    float4 scale_id;    // s.xyz, particle id (bits)
-    float4 feat;        // max(rgb,0), unused
-};
-
-constexpr int kGradRow = 16;  // floats per gradient row: pos3, density, quat4, scale3, rgb3, pad2
-
-// d(out)/d(quat) for out = rotationT(q) * p, given g = dL/d(out)   (common/mathUtils.cuh:468-533)
-__device__ __forceinline__ void matmul_bw_quat(float p0, float p1, float p2, float g0, float g1, float g2, float r,
-                                               float x, float y, float z, float& dr, float& dx, float& dy, float& dz) {
-    const float d00 = g0 * p0, d01 = g0 * p1, d02 = g0 * p2;
-    const float d10 = g1 * p0, d11 = g1 * p1, d12 = g1 * p2;
-    const float d20 = g2 * p0, d21 = g2 * p1, d22 = g2 * p2;
-    dr += 2.0f * (z * (d01 - d10) + y * (d20 - d02) + x * (d12 - d21));
-    dx += 2.0f * (y * (d01 + d10) + z * (d02 + d20) + r * (d12 - d21)) - 4.0f * x * (d11 + d22);
-    dy += 2.0f * (x * (d01 + d10) + r * (d20 - d02) + z * (d12 + d21)) - 4.0f * y * (d00 + d22);
-    dz += 2.0f * (r * (d01 - d10) + x * (d02 + d20) + y * (d12 + d21)) - 4.0f * z * (d00 + d11);
+template <int kCtrl, int kRowMask = 0xF, int kBankMask = 0xF>
+__device__ __forceinline__ float dpp_mov(float oldv, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, v),
+                                                                 kCtrl, kRowMask, kBankMask, false));
 }
 
+// Sums each of the 16 values of v[] over the 64 lanes.  On return lane 48+k (k = 0..15) holds in its return value
+// the wave total of v[slot(k)], slot(k) = 8*(k&1) + 4*((k>>1)&1) + 2*((k>>2)&1) + ((k>>3)&1).
+__device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], uint32_t lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // partner = lane ^ 1 (quad_perm [1,0,3,2])
+        const float keep = b0 ? v[8 + i] : v[i];
+        const float send = b0 ? v[i] : v[8 + i];
+        a[i] = keep + dpp_mov<0xB1>(0.f, send);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // partner = lane ^ 2 (quad_perm [2,3,0,1])
+        const float keep = b1 ? a[4 + i] : a[i];
+        const float send = b1 ? a[i] : a[4 + i];
+        b[i] = keep + dpp_mov<0x4E>(0.f, send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // partner = lane ^ 4: row_shl:4 feeds banks 0,2 ; row_shr:4 feeds banks 1,3
+        const float keep = b2 ? b[2 + i] : b[i];
+        const float send = b2 ? b[i] : b[2 + i];
+        float recv = dpp_mov<0x104, 0xF, 0x5>(0.f, send);
+        recv = dpp_mov<0x114, 0xF, 0xA>(recv, send);
+        c[i] = keep + recv;
+    }
+    float r;
+    {  // partner = lane ^ 8 (row_ror:8)
+        const float keep = b3 ? c[1] : c[0];
+        const float send = b3 ? c[0] : c[1];
+        r = keep + dpp_mov<0x128>(0.f, send);
+    }
+    return r;  // lane l: total over its 16-lane row of v[slot(l & 15)]; the 4 rows are combined by the LDS atomic
+}
+
+__device__ __forceinline__ uint32_t reduce_slot(uint32_t lane) {
+    return 8u * (lane & 1u) + 4u * ((lane >> 1) & 1u) + 2u * ((lane >> 2) & 1u) + ((lane >> 3) & 1u);
+}
+
+constexpr int kGradRow = 16;  // floats per global gradient row: pos3, density, quat4, scale3, rgb3, pad2
+
+// accumulator slots inside a chunk row
+//   0..8  A[i][j] = sum h_i m_j     9..11 H_i = sum h_i     12 d(density)     13..15 d(rgb)     [16..18 direct d(scale)]
+template <bool kDistGrad>
+struct AccLayout {
+    static constexpr int kW = kDistGrad ? 20 : 16;
+};
+
+template <bool kDistGrad>
 __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, RenderConsts c,
                                                            const float4* __restrict__ density12,
                                                            const float* __restrict__ feat,
@@ -274,8 +321,9 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
                                                            const float4* __restrict__ rgba_grad,
                                                            const float* __restrict__ dist_grad, float* __restrict__ grad16,
                                                            uint32_t* __restrict__ tile_traversed) {
-    __shared__ BwdEntry stage[kBlock];
-    __shared__ float acc[kBlock * kGradRow];
+    constexpr int W = AccLayout<kDistGrad>::kW;
+    __shared__ FwdEntry stage[kBlock];
+    __shared__ float acc[kBlock * W];
     __shared__ uint32_t s_deepest;
 
     const uint32_t tile = blockIdx.x;
@@ -289,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
 
     if (tid == 0) s_deepest = 0;
 #pragma unroll
-    for (int k = 0; k < kGradRow; ++k) acc[k * kBlock + tid] = 0.0f;
+    for (int k = 0; k < W; ++k) acc[k * kBlock + tid] = 0.0f;
 
     // forward results and upstream gradients of this pixel (rayPayloadBackward.cuh:30-58)
     float T_final = 1.f, Tg = 0.f, fr = 0.f, fg = 0.f, fb = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f;
@@ -300,11 +348,12 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
         Tg = -g.w;  // transmittanceGradient = -dL/d(opacity)
         fr = o.x; fg = o.y; fb = o.z;
         gr = g.x; gg = g.y; gb = g.z;
-        gd = dist_grad[pix];
+        if (kDistGrad) gd = dist_grad[pix];
     }
 
     const uint2 range = ranges[tile];
     const uint32_t total = range.y - range.x;
+    const uint32_t my_slot = reduce_slot(lane);
     bool alive = ray.valid;
     float T = 1.0f, rr = 0.f, rg = 0.f, rb = 0.f;  // running transmittance / radiance
     uint32_t consumed = 0;
@@ -315,22 +364,22 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
             const uint32_t k = range.x + base + tid;
             uint32_t id = kInvalid;
             if (k < range.y) id = sorted_ids[k];
-            BwdEntry e;
-            e.scale_id.w = __uint_as_float(id);
+            FwdEntry e;
+            e.feat_id.w = __uint_as_float(id);
             if (id != kInvalid) {
                 const float4 a = density12[3 * (size_t)id + 0];
                 const float4 q = density12[3 * (size_t)id + 1];
-                const float4 s = density12[3 * (size_t)id + 2];
+                const float4 sc = density12[3 * (size_t)id + 2];
                 float r[3][3];
                 quat_rows(q.x, q.y, q.z, q.w, r);
+                const float i0 = 1.0f / sc.x, i1 = 1.0f / sc.y, i2 = 1.0f / sc.z;
                 e.mu_sigma = a;
-                e.quat = q;
-                e.r0 = make_float4(r[0][0], r[0][1], r[0][2], 1.0f / s.x);
-                e.r1 = make_float4(r[1][0], r[1][1], r[1][2], 1.0f / s.y);
-                e.r2 = make_float4(r[2][0], r[2][1], r[2][2], 1.0f / s.z);
-                e.scale_id.x = s.x; e.scale_id.y = s.y; e.scale_id.z = s.z;
-                e.feat = make_float4(fmaxf(feat[3 * (size_t)id + 0], 0.0f), fmaxf(feat[3 * (size_t)id + 1], 0.0f),
-                                     fmaxf(feat[3 * (size_t)id + 2], 0.0f), 0.0f);
+                e.m0 = make_float4(r[0][0] * i0, r[0][1] * i0, r[0][2] * i0, sc.x);
+                e.m1 = make_float4(r[1][0] * i1, r[1][1] * i1, r[1][2] * i1, sc.y);
+                e.m2 = make_float4(r[2][0] * i2, r[2][1] * i2, r[2][2] * i2, sc.z);
+                e.feat_id.x = fmaxf(feat[3 * (size_t)id + 0], 0.0f);
+                e.feat_id.y = fmaxf(feat[3 * (size_t)id + 1], 0.0f);
+                e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
             }
             stage[tid] = e;
         }
@@ -339,134 +388,177 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
         const uint32_t cnt = min((uint32_t)kBlock, total - base);
         for (uint32_t j = 0; j < cnt; ++j) {
             if (__ballot(alive) == 0ull) break;
-            const float4 sid = stage[j].scale_id;
-            if (__float_as_uint(sid.w) == kInvalid) {
+            const float4 fid = stage[j].feat_id;
+            if (__float_as_uint(fid.w) == kInvalid) {
                 alive = false;
                 break;
             }
-            float g[14];
-#pragma unroll
-            for (int k = 0; k < 14; ++k) g[k] = 0.0f;
+            float g[16];
+            float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;  // direct scale terms (kDistGrad only)
             bool hit = false;
             if (alive) {
                 consumed = base + j + 1;
                 const float4 ms = stage[j].mu_sigma;
-                const float4 r0 = stage[j].r0, r1 = stage[j].r1, r2 = stage[j].r2;
-                const float p0 = ray.ox - ms.x, p1 = ray.oy - ms.y, p2 = ray.oz - ms.z;      // gposc
-                const float pr0 = r0.x * p0 + r0.y * p1 + r0.z * p2;                           // gposcr
-                const float pr1 = r1.x * p0 + r1.y * p1 + r1.z * p2;
-                const float pr2 = r2.x * p0 + r2.y * p1 + r2.z * p2;
-                const float dr0 = r0.x * ray.dx + r0.y * ray.dy + r0.z * ray.dz;               // rayDirR
-                const float dr1 = r1.x * ray.dx + r1.y * ray.dy + r1.z * ray.dz;
-                const float dr2 = r2.x * ray.dx + r2.y * ray.dy + r2.z * ray.dz;
-                const float o0 = pr0 * r0.w, o1 = pr1 * r1.w, o2 = pr2 * r2.w;                 // gro
-                const float u0 = dr0 * r0.w, u1 = dr1 * r1.w, u2 = dr2 * r2.w;                 // grdu
+                const float4 m0 = stage[j].m0, m1 = stage[j].m1, m2 = stage[j].m2;
+                const float p0 = ray.ox - ms.x, p1 = ray.oy - ms.y, p2 = ray.oz - ms.z;
+                const float o0 = m0.x * p0 + m0.y * p1 + m0.z * p2;
+                const float o1 = m1.x * p0 + m1.y * p1 + m1.z * p2;
+                const float o2 = m2.x * p0 + m2.y * p1 + m2.z * p2;
+                const float u0 = m0.x * ray.dx + m0.y * ray.dy + m0.z * ray.dz;
+                const float u1 = m1.x * ray.dx + m1.y * ray.dy + m1.z * ray.dz;
+                const float u2 = m2.x * ray.dx + m2.y * ray.dy + m2.z * ray.dz;
+                const float c0 = u1 * o2 - u2 * o1, c1 = u2 * o0 - u0 * o2, c2 = u0 * o1 - u1 * o0;
                 const float l2 = u0 * u0 + u1 * u1 + u2 * u2;
-                const float il = l2 > 0.0f ? fast_rsq(l2) : 1.0f;
-                const float d0 = u0 * il, d1 = u1 * il, d2_ = u2 * il;                         // grd
-                const float c0 = d1 * o2 - d2_ * o1, c1 = d2_ * o0 - d0 * o2, c2 = d0 * o1 - d1 * o0;
-                const float dsq = c0 * c0 + c1 * c1 + c2 * c2;
-                if (dsq < c.max_d2) {
-                    const float resp = fast_exp(-0.5f * dsq);
-                    const float alpha = fminf(c.max_alpha, resp * ms.w);
+                const float il2 = fast_rcp(l2);
+                const float d2 = (c0 * c0 + c1 * c1 + c2 * c2) * il2;
+                if (d2 < c.max_d2) {
+                    const float resp = fast_exp(-0.5f * d2);
+                    const float a0 = resp * ms.w;
+                    const float alpha = fminf(c.max_alpha, a0);
                     if ((resp > c.min_response) && (alpha > c.alpha_threshold)) {  // NB: no tmin/tmax test in the backward
                         hit = true;
-                        const float4 q = stage[j].quat;
-                        const float4 ft = stage[j].feat;
-                        const float proj = -(d0 * o0 + d1 * o1 + d2_ * o2);
-                        const float dd0 = d0 * proj, dd1 = d1 * proj, dd2 = d2_ * proj;       // grdd
-                        const float s0 = sid.x * dd0, s1 = sid.y * dd1, s2 = sid.z * dd2;       // grds
-                        const float gsq = s0 * s0 + s1 * s1 + s2 * s2;
-                        const float gdist = sqrtf(gsq);
                         const float w = alpha * T;
                         const float Tn = (1.0f - alpha) * T;
-                        // hit-distance terms (residualHitT == 0: quirk 1 of SURVEY §8a)
-                        const float ga_hit = gdist * T * gd;
-                        float k0 = 0.f, k1 = 0.f, k2 = 0.f;  // grdsRayHitGrd
-                        if (gsq > 0.0f) {
-                            const float kk = (w / gdist) * gd;
-                            k0 = s0 * kk; k1 = s1 * kk; k2 = s2 * kk;
+                        const float t = (u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (u.o)/|u|^2
+                        const float q0 = o0 - t * u0, q1 = o1 - t * u1, q2 = o2 - t * u2;  // o_perp
+                        float ga_hit = 0.f;
+                        float k0 = 0.f, k1 = 0.f, k2 = 0.f, d0 = 0.f, d1 = 0.f, d2n = 0.f, il = 0.f;
+                        if (kDistGrad) {
+                            // hit-distance terms (residualHitT == 0: quirk 1 of SURVEY §8a); grd = u/|u|
+                            il = fast_rsq(l2);
+                            d0 = u0 * il; d1 = u1 * il; d2n = u2 * il;
+                            const float proj = -(d0 * o0 + d1 * o1 + d2n * o2);
+                            const float s0 = m0.w * d0 * proj, s1 = m1.w * d1 * proj, s2 = m2.w * d2n * proj;  // grds
+                            const float gsq = s0 * s0 + s1 * s1 + s2 * s2;
+                            const float gdist = sqrtf(gsq);
+                            ga_hit = gdist * T * gd;
+                            if (gsq > 0.0f) {
+                                const float kk = (w / gdist) * gd;
+                                k0 = s0 * kk; k1 = s1 * kk; k2 = s2 * kk;  // grdsRayHitGrd
+                            }
+                            gs0 = d0 * proj * k0; gs1 = d1 * proj * k1; gs2 = d2n * proj * k2;  // gsclRayHitGrd
                         }
-                        const float x0 = d0 * o0, x1 = d1 * o1, x2 = d2_ * o2;
-                        const float hd0 = -sid.x * (2.0f * x0 + x1 + x2) * k0;                   // grdRayHitGrd
-                        const float hd1 = -sid.y * (x0 + 2.0f * x1 + x2) * k1;
-                        const float hd2 = -sid.z * (x0 + x1 + 2.0f * x2) * k2;
-                        const float ho0 = -sid.x * d0 * d0 * k0;                                 // groRayHitGrd
-                        const float ho1 = -sid.y * d1 * d1 * k1;
-                        const float ho2 = -sid.z * d2_ * d2_ * k2;
                         const float res_T = alpha < 0.999999f ? T_final * fast_rcp(1.0f - alpha) : T;
                         const float ga_dns = res_T * -Tg;
-                        // radiance: dL/dRGB of this particle, running radiance, residual radiance behind it
-                        g[11] = gr * w; g[12] = gg * w; g[13] = gb * w;
-                        rr += w * ft.x; rg += w * ft.y; rb += w * ft.z;
-                        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                        g[13] = gr * w; g[14] = gg * w; g[15] = gb * w;
+                        rr += w * fid.x; rg += w * fid.y; rb += w * fid.z;
+                        float e0 = 0.f, e1 = 0.f, e2 = 0.f;  // residual radiance behind this particle
                         if (!(Tn <= c.min_transmittance)) {
                             const float iT = fast_rcp(Tn);
-                            q0 = fmaxf((fr - rr) * iT, 0.0f);
-                            q1 = fmaxf((fg - rg) * iT, 0.0f);
-                            q2 = fmaxf((fb - rb) * iT, 0.0f);
+                            e0 = fmaxf((fr - rr) * iT, 0.0f);
+                            e1 = fmaxf((fg - rg) * iT, 0.0f);
+                            e2 = fmaxf((fb - rb) * iT, 0.0f);
                         }
-                        const float G = ga_hit + ga_dns + T * ((ft.x - q0) * gr + (ft.y - q1) * gg + (ft.z - q2) * gb);
-                        g[3] = resp * G;                          // d density
-                        const float g_resp = ms.w * G;
-                        const float g_d2 = -0.5f * resp * g_resp;
-                        const float e0 = 2.0f * c0 * g_d2, e1 = 2.0f * c1 * g_d2, e2 = 2.0f * c2 * g_d2;  // d cross
-                        const float gd0 = e2 * o1 - e1 * o2 + hd0;  // d grd (incl. hit term)
-                        const float gd1 = e0 * o2 - e2 * o0 + hd1;
-                        const float gd2 = e1 * o0 - e0 * o1 + hd2;
-                        const float go0 = e1 * d2_ - e2 * d1 + ho0;  // d gro (incl. hit term)
-                        const float go1 = e2 * d0 - e0 * d2_ + ho1;
-                        const float go2 = e0 * d1 - e1 * d0 + ho2;
-                        const float gp0 = go0 * r0.w, gp1 = go1 * r1.w, gp2 = go2 * r2.w;        // d gposcr
-                        // d position = -(rotationT^T * d gposcr)
-                        g[0] = -(gp0 * r0.x + gp1 * r1.x + gp2 * r2.x);
-                        g[1] = -(gp0 * r0.y + gp1 * r1.y + gp2 * r2.y);
-                        g[2] = -(gp0 * r0.z + gp1 * r1.z + gp2 * r2.z);
-                        // d grdu = (I - grd grd^T)/|grdu| * d grd      (safe_normalize_bw, mathUtils.cuh:420-430)
-                        float gu0 = 0.f, gu1 = 0.f, gu2 = 0.f;
-                        if (l2 > 0.0f) {
-                            const float dot = gd0 * d0 + gd1 * d1 + gd2 * d2_;
-                            gu0 = il * (gd0 - d0 * dot);
-                            gu1 = il * (gd1 - d1 * dot);
-                            gu2 = il * (gd2 - d2_ * dot);
+                        const float G = ga_hit + ga_dns + T * ((fid.x - e0) * gr + (fid.y - e1) * gg + (fid.z - e2) * gb);
+                        g[12] = resp * G;                      // d density
+                        const float g_d2x2 = -a0 * G;          // 2 * dL/d(d2) = 2 * (-1/2 resp sigma G)
+                        float h0 = g_d2x2 * q0, h1 = g_d2x2 * q1, h2 = g_d2x2 * q2;  // dL/do
+                        if (!kDistGrad) {
+                            const float n0 = p0 - t * ray.dx, n1 = p1 - t * ray.dy, n2 = p2 - t * ray.dz;  // m
+                            g[0] = h0 * n0; g[1] = h0 * n1; g[2] = h0 * n2;
+                            g[3] = h1 * n0; g[4] = h1 * n1; g[5] = h1 * n2;
+                            g[6] = h2 * n0; g[7] = h2 * n1; g[8] = h2 * n2;
+                        } else {
+                            float v0 = -t * h0, v1 = -t * h1, v2 = -t * h2;  // dL/du from the response term
+                            // reference's diagonal hit-distance terms: d/d(gro) and d/d(grd) (gaussianParticles.cuh:559-567)
+                            const float x0 = d0 * o0, x1 = d1 * o1, x2 = d2n * o2;
+                            h0 += -m0.w * d0 * d0 * k0;
+                            h1 += -m1.w * d1 * d1 * k1;
+                            h2 += -m2.w * d2n * d2n * k2;
+                            const float hd0 = -m0.w * (2.0f * x0 + x1 + x2) * k0;
+                            const float hd1 = -m1.w * (x0 + 2.0f * x1 + x2) * k1;
+                            const float hd2 = -m2.w * (x0 + x1 + 2.0f * x2) * k2;
+                            const float dot = hd0 * d0 + hd1 * d1 + hd2 * d2n;  // safe_normalize_bw
+                            v0 += il * (hd0 - d0 * dot);
+                            v1 += il * (hd1 - d1 * dot);
+                            v2 += il * (hd2 - d2n * dot);
+                            g[0] = h0 * p0 + v0 * ray.dx; g[1] = h0 * p1 + v0 * ray.dy; g[2] = h0 * p2 + v0 * ray.dz;
+                            g[3] = h1 * p0 + v1 * ray.dx; g[4] = h1 * p1 + v1 * ray.dy; g[5] = h1 * p2 + v1 * ray.dz;
+                            g[6] = h2 * p0 + v2 * ray.dx; g[7] = h2 * p1 + v2 * ray.dy; g[8] = h2 * p2 + v2 * ray.dz;
                         }
-                        // d scale
-                        g[8] = dd0 * k0 - o0 * r0.w * go0 - u0 * r0.w * gu0;
-                        g[9] = dd1 * k1 - o1 * r1.w * go1 - u1 * r1.w * gu1;
-                        g[10] = dd2 * k2 - o2 * r2.w * go2 - u2 * r2.w * gu2;
-                        // d quaternion through both mat-vecs
-                        float qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
-                        matmul_bw_quat(p0, p1, p2, gp0, gp1, gp2, q.x, q.y, q.z, q.w, qr, qx, qy, qz);
-                        matmul_bw_quat(ray.dx, ray.dy, ray.dz, gu0 * r0.w, gu1 * r1.w, gu2 * r2.w, q.x, q.y, q.z, q.w, qr,
-                                       qx, qy, qz);
-                        g[4] = qr; g[5] = qx; g[6] = qy; g[7] = qz;
+                        g[9] = h0; g[10] = h1; g[11] = h2;
                         T = Tn;
                         if (T < c.min_transmittance) alive = false;
                     }
                 }
             }
             if (__ballot(hit) != 0ull) {  // wave-uniform: skip the reduction when no lane of this wave hit entry j
+                if (!hit) {
 #pragma unroll
-                for (int k = 0; k < 14; ++k) {
-                    const float s = wave_sum_lane63(g[k]);
-                    if (lane == 63) atomicAdd(&acc[j * kGradRow + k], s);
+                    for (int k = 0; k < 16; ++k) g[k] = 0.0f;
+                }
+                const float r = wave_transpose_reduce16(g, lane);
+                atomicAdd(&acc[j * W + my_slot], r);  // one ds_add_f32 for the whole wave (4 rows share 16 addresses)
+                if (kDistGrad) {
+                    const float t0 = wave_sum_lane63(gs0), t1 = wave_sum_lane63(gs1), t2 = wave_sum_lane63(gs2);
+                    if (lane == 63) {
+                        atomicAdd(&acc[j * W + 16], t0);
+                        atomicAdd(&acc[j * W + 17], t1);
+                        atomicAdd(&acc[j * W + 18], t2);
+                    }
                 }
             }
         }
 
-        // flush this chunk's accumulators: one float atomic per (entry, component); a wave-instruction covers
-        // 4 entries x 16 consecutive floats of their 64-byte gradient rows
+        // ---- chunk epilogue: (A, H) -> d(position), d(scale), d(quaternion), one entry per lane ----
         __syncthreads();
+        if (tid < cnt) {
+            float* a = &acc[tid * W];
+            const uint32_t id = __float_as_uint(stage[tid].feat_id.w);
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < W; ++k) any = any || (a[k] != 0.0f);
+            if (any && id != kInvalid) {
+                const float4 q = density12[3 * (size_t)id + 1];
+                const float4 sc = density12[3 * (size_t)id + 2];
+                float r[3][3];
+                quat_rows(q.x, q.y, q.z, q.w, r);
+                const float is[3] = {1.0f / sc.x, 1.0f / sc.y, 1.0f / sc.z};
+                const float A[3][3] = {{a[0], a[1], a[2]}, {a[3], a[4], a[5]}, {a[6], a[7], a[8]}};
+                const float H[3] = {a[9], a[10], a[11]};
+                const float d_dens = a[12], d_r = a[13], d_g = a[14], d_b = a[15];
+                float out[16];
+                // d mu = -M^T H
+                out[0] = -(is[0] * r[0][0] * H[0] + is[1] * r[1][0] * H[1] + is[2] * r[2][0] * H[2]);
+                out[1] = -(is[0] * r[0][1] * H[0] + is[1] * r[1][1] * H[1] + is[2] * r[2][1] * H[2]);
+                out[2] = -(is[0] * r[0][2] * H[0] + is[1] * r[1][2] * H[1] + is[2] * r[2][2] * H[2]);
+                out[3] = d_dens;
+                // d s_i = -(1/s_i)^2 sum_j A_ij R_ij  (+ direct hit-distance term)
+                float ds[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    ds[i] = -is[i] * is[i] * (A[i][0] * r[i][0] + A[i][1] * r[i][1] + A[i][2] * r[i][2]);
+                if (kDistGrad) { ds[0] += a[16]; ds[1] += a[17]; ds[2] += a[18]; }
+                // d q through rotationT(q): dmat_ij = dL/dR_ij = (1/s_i) A_ij   (matmul_bw_quat, mathUtils.cuh:468-533)
+                const float d00 = is[0] * A[0][0], d01 = is[0] * A[0][1], d02 = is[0] * A[0][2];
+                const float d10 = is[1] * A[1][0], d11 = is[1] * A[1][1], d12 = is[1] * A[1][2];
+                const float d20 = is[2] * A[2][0], d21 = is[2] * A[2][1], d22 = is[2] * A[2][2];
+                const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+                out[4] = 2.0f * (qz * (d01 - d10) + qy * (d20 - d02) + qx * (d12 - d21));
+                out[5] = 2.0f * (qy * (d01 + d10) + qz * (d02 + d20) + qr * (d12 - d21)) - 4.0f * qx * (d11 + d22);
+                out[6] = 2.0f * (qx * (d01 + d10) + qr * (d20 - d02) + qz * (d12 + d21)) - 4.0f * qy * (d00 + d22);
+                out[7] = 2.0f * (qr * (d01 - d10) + qx * (d02 + d20) + qy * (d12 + d21)) - 4.0f * qz * (d00 + d11);
+                out[8] = ds[0]; out[9] = ds[1]; out[10] = ds[2];
+                out[11] = d_r; out[12] = d_g; out[13] = d_b;
+                out[14] = 0.0f; out[15] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] = out[k];
+            }
+        }
+        __syncthreads();
+        // flush: one global float atomic per (entry, component); a wave-instruction covers 4 entries x 16 consecutive
+        // floats of their 64-byte gradient rows
 #pragma unroll 4
         for (uint32_t it = 0; it < kBlock / 16; ++it) {
             const uint32_t e = it * 16 + (tid >> 4);
             const uint32_t k = tid & 15;
-            const float val = acc[e * kGradRow + k];
-            if (val != 0.0f) {
-                const uint32_t id = __float_as_uint(stage[e].scale_id.w);
+            const float val = acc[e * W + k];
+            if (val != 0.0f && k < 14) {
+                const uint32_t id = __float_as_uint(stage[e].feat_id.w);
                 atomicAdd(&grad16[(size_t)id * kGradRow + k], val);
-                acc[e * kGradRow + k] = 0.0f;
             }
+            acc[e * W + k] = 0.0f;
+            if (kDistGrad && k < 4) acc[e * W + 16 + k] = 0.0f;
         }
     }
 
@@ -492,7 +584,8 @@ void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c
                        float* grad16, uint32_t* tile_traversed) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
-    hipLaunchKernelGGL(k_render_backward, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12),
+    auto kern = dist_grad != nullptr ? k_render_backward<true> : k_render_backward<false>;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
                        reinterpret_cast<const float4*>(rgba), reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
                        tile_traversed);

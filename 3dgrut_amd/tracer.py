@@ -212,7 +212,7 @@ class SplatRaster:
         rgba = _check_f32_cuda(ray_radiance_density, "rayRadianceDensity", (4,))
         rgba_g = _check_f32_cuda(ray_radiance_density_grd, "rayRadianceDensityGradient", (4,))
         dist = _check_f32_cuda(ray_hit_distance, "rayHitDistance")
-        dist_g = _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
+        dist_g = None if ray_hit_distance_grd is None else _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
         opts = dict(dtype=torch.float32, device=dev)
         dens_g = torch.empty((n, 12), **opts)  # fully written by the per-Gaussian epilogue kernel
         sph_g = torch.empty((n, 48), **opts)
@@ -227,7 +227,7 @@ class SplatRaster:
                                          particle_density.data_ptr() if n else None,
                                          particle_radiance.data_ptr() if n else None, W, H, ray_ori.data_ptr(),
                                          ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(), rgba_g.data_ptr(),
-                                         dist.data_ptr(), dist_g.data_ptr(), dens_g.data_ptr() if n else None,
+                                         dist.data_ptr(), None if dist_g is None else dist_g.data_ptr(), dens_g.data_ptr() if n else None,
                                          sph_g.data_ptr() if n else None)
         _capi.check(rc, "trace_bwd")
         return dens_g, sph_g
@@ -297,6 +297,7 @@ class Tracer:
             ctx.sensor_poses = sensor_poses
             ctx.tracer_wrapper = tracer_wrapper
             ctx.mark_non_differentiable(hits, vis)
+            ctx.set_materialize_grads(False)  # an unused pred_dist arrives as None -> backward variant without dist terms
             return rgba, dist, hits, vis
 
         @staticmethod
@@ -305,12 +306,10 @@ class Tracer:
             poses = ctx.sensor_poses
             if rgba_grd is None:
                 rgba_grd = torch.zeros_like(rgba)
-            if dist_grd is None:
-                dist_grd = torch.zeros_like(dist)
             dens_grd, sph_grd = ctx.tracer_wrapper.trace_bwd(
                 ctx.frame_id, ctx.n_active_features, particle_density, particle_radiance, ray_ori, ray_dir, None,
                 ctx.sensor_params, poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0],
-                poses.T_world_sensors[1], rgba, rgba_grd.contiguous(), dist, dist_grd.contiguous())
+                poses.T_world_sensors[1], rgba, rgba_grd.contiguous(), dist, None if dist_grd is None else dist_grd.contiguous())
             pos_g, dns_g, rot_g, scl_g, _ = torch.split(dens_grd, [3, 1, 4, 3, 1], dim=1)  # tracer.py:268-270
             return (None, None, None, None, None, pos_g.contiguous(), rot_g.contiguous(), scl_g.contiguous(),
                     dns_g.contiguous(), sph_grd, None, None)

@@ -130,7 +130,8 @@ int gut_trace(gut_handle h, void* stream, uint32_t frame_number, int32_t num_act
               float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
               float* d_particle_visibility);
 
-/* SplatRaster::traceBwd — splatRaster.cpp:247-332.  Gradient outputs are fully overwritten:
+/* SplatRaster::traceBwd — splatRaster.cpp:247-332.  d_ray_hit_distance_grad may be NULL (treated as zeros; selects
+ * the kernel variant without hit-distance gradient terms).  Gradient outputs are fully overwritten:
  *   d_particle_density_grad f32 [N,12], d_particle_radiance_grad f32 [N,48]                       */
 int gut_trace_bwd(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features,
                   uint32_t num_particles, const float* d_particle_density, const float* d_particle_radiance,
