@@ -53,7 +53,8 @@ class GutStats(C.Structure):
 
 
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
-           "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version")
+           "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
+           "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward")
 
 _lib = None
 
@@ -85,6 +86,11 @@ def load():
     lib.gut_debug_copy.argtypes = [vp, i32, vp, C.c_size_t]
     lib.gut_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]
     lib.gut_kernel_times_mean.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    i64 = C.c_int64
+    lib.gut_ssim_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.gut_ssim_workspace_bytes.restype = C.c_size_t
+    lib.gut_ssim_forward.argtypes = [vp, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp]
+    lib.gut_ssim_backward.argtypes = [vp, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
     _lib = lib

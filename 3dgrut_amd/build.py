@@ -20,6 +20,7 @@ UNITS = [
     ("gut_project.hip", ["-ffp-contract=off"]),
     ("gut_render.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics"]),
     ("gut_sort.hip", ["-Wno-unused-parameter"]),
+    ("gut_ssim.hip", ["-ffp-contract=fast"]),
     ("gut_api.cpp", ["-x", "hip", "-ffp-contract=off"]),
 ]
 

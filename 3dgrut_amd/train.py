@@ -8,8 +8,8 @@
     optimizer.step(); optimizer.zero_grad()     (Adam, eps 1e-15, reference learning rates)
 
 The reference's SSIM is the external CUDA-only `fused_ssim` package (model/losses.py:17-33,
-requirements.txt:23); here it is a separable 11-tap Gaussian-window SSIM written with torch convolutions
-(`padding="valid"` like the reference call) — a stand-in until the HIP SSIM kernel of SURVEY §8f-N1 lands.
+requirements.txt:23); here it is the HIP kernel pair of csrc/gut_ssim.hip (losses.fused_ssim, same call
+signature, `padding="valid"`).  `ssim()` below is the plain-torch fp32/fp64 reference the tests check it against.
 Per-view data parallelism: one process per GPU, full replica, rank r renders view
 step*world+r, gradients are summed with an RCCL all-reduce and divided by the world size.
 """
@@ -18,6 +18,8 @@ import math
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
+
+from .losses import photometric_loss
 
 
 def _gauss_window(size=11, sigma=1.5, device="cpu", dtype=torch.float32):
@@ -47,7 +49,7 @@ def ssim(img1, img2, window=None):
     return m.mean()
 
 
-def photometric_loss(pred_rgb, gt_rgb, lambda_l1=0.8, lambda_ssim=0.2, window=None):
+def photometric_loss_torch(pred_rgb, gt_rgb, lambda_l1=0.8, lambda_ssim=0.2, window=None):
     """pred/gt: [B,H,W,3].  0.8*L1 + 0.2*(1-SSIM) (trainer.py:449)."""
     l1 = (pred_rgb - gt_rgb).abs().mean()
     s = ssim(pred_rgb.permute(0, 3, 1, 2), gt_rgb.permute(0, 3, 1, 2), window)
@@ -71,7 +73,7 @@ class TrainStep:
 
     def step(self, batch):
         out = self.render(batch, train=True)
-        loss = photometric_loss(out["pred_rgb"], batch.rgb_gt, window=self.window)
+        loss = photometric_loss(out["pred_rgb"], batch.rgb_gt)
         loss.backward()
         if self.world_size > 1:
             self.allreduce_gradients()

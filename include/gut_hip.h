@@ -161,6 +161,19 @@ int gut_kernel_times(gut_handle h, float* ms8);
  * function; *count = number of forward calls averaged.  Synchronises. */
 int gut_kernel_times_mean(gut_handle h, float* ms8, int32_t* count);
 
+/* ---- "next" row N1: fused SSIM, replaces the external CUDA package `fused_ssim`
+ * (threedgrut/model/losses.py:17-33: fused_ssim(img1, img2, padding="valid")).  Mean SSIM of two images with an
+ * 11x11 Gaussian window (sigma 1.5), valid padding.  Images are addressed with element strides (channel, row,
+ * pixel) so NCHW and NHWC tensors are both consumed in place.  Workspace (derivative maps + partial sums) is
+ * caller-owned device memory of gut_ssim_workspace_bytes(); backward consumes the workspace its forward filled.
+ * Return 0 on success. */
+size_t gut_ssim_workspace_bytes(int32_t channels, int32_t height, int32_t width);
+int gut_ssim_forward(void* stream, int32_t channels, int32_t height, int32_t width, int64_t stride_c, int64_t stride_h,
+                     int64_t stride_w, const float* d_img1, const float* d_img2, void* d_workspace, float* d_mean_ssim);
+int gut_ssim_backward(void* stream, int32_t channels, int32_t height, int32_t width, int64_t stride_c, int64_t stride_h,
+                      int64_t stride_w, const float* d_img1, const float* d_img2, const void* d_workspace,
+                      const float* d_upstream, float* d_grad_img1);
+
 const char* gut_last_error(void);
 int gut_abi_version(void);
 
