@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  #
 
 GUT_ABI_VERSION = 1
 GUT_NUM_KERNEL_TIMERS = 8
+BWD_RAW_PARAMETER_GRADS = 1
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd")
 
 SHUTTER_GLOBAL = 4
@@ -54,7 +55,8 @@ class GutStats(C.Structure):
 
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
-           "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward")
+           "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
+           "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step")
 
 _lib = None
 
@@ -91,6 +93,11 @@ def load():
     lib.gut_ssim_workspace_bytes.restype = C.c_size_t
     lib.gut_ssim_forward.argtypes = [vp, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp]
     lib.gut_ssim_backward.argtypes = [vp, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.gut_trace_bwd_ex.argtypes = [vp, vp, u32, i32, u32, f_p, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera),
+                                     f_p, f_p, f_p, f_p, f_p, f_p, u32]
+    lib.gut_activate_pack.argtypes = [vp, u32, vp, vp]
+    lib.gut_adam_step.argtypes = [vp, C.c_uint64, u32, vp, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float,
+                                  C.c_float, u32, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
     _lib = lib

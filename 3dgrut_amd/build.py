@@ -21,6 +21,7 @@ UNITS = [
     ("gut_render.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics"]),
     ("gut_sort.hip", ["-Wno-unused-parameter"]),
     ("gut_ssim.hip", ["-ffp-contract=fast"]),
+    ("gut_train.hip", ["-ffp-contract=fast"]),
     ("gut_api.cpp", ["-x", "hip", "-ffp-contract=off"]),
 ]
 

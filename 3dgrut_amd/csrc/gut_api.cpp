@@ -436,12 +436,31 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     return 0;
 }
 
+int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                     const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+                     const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                     const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                     const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_particle_density_grad,
+                     float* d_particle_radiance_grad, uint32_t flags);
+
 int gut_trace_bwd(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
                   const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
                   const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
                   const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
                   const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_particle_density_grad,
                   float* d_particle_radiance_grad) {
+    return gut_trace_bwd_ex(h, stream_, frame_number, num_active_features, num_particles, d_particle_density, d_particle_radiance,
+                            width, height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density,
+                            d_ray_radiance_density_grad, d_ray_hit_distance, d_ray_hit_distance_grad, d_particle_density_grad,
+                            d_particle_radiance_grad, 0u);
+}
+
+int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                     const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+                     const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                     const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                     const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_particle_density_grad,
+                     float* d_particle_radiance_grad, uint32_t flags) {
     (void)frame_number;
     (void)d_particle_radiance;
     (void)d_ray_hit_distance;
@@ -485,7 +504,8 @@ int gut_trace_bwd(gut_handle h, void* stream_, uint32_t frame_number, int32_t nu
                                h->trav_bwd.as<uint32_t>());
     mark(10);
     gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
-                            h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad);
+                            h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad,
+                            (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0);
     mark(11);
     HIP_TRY(hipGetLastError());
     if (total) {

@@ -61,7 +61,7 @@ void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, ui
 void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, uint32_t* ranges);
 void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
                         const uint32_t* tiles_count, const float* feat, const float* grad16,
-                        float* density_grad12, float* sph_grad48);
+                        float* density_grad12, float* sph_grad48, bool raw_grads);
 
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,

@@ -577,6 +577,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_ranges(uint32_t m, const uint64
 // (pos3, density, quat4, scale3, dRGB3, pad2), writes the [N,12] density gradient and the [N,48] SH
 // gradient in full (zeros for Gaussians that touched no tile), so the caller never zero-fills them.
 // ---------------------------------------------------------------------------------------------------
+// kRawGrads: additionally chain d(position, density, quaternion, scale) through the model's activations
+// (sigmoid, normalise, exp — threedgrut/model/model.py:74-93) so that the rows can be fed to the optimiser as
+// gradients of the RAW parameters; |quat| is read from the pad column written by k_activate_pack.
+template <bool kRawGrads>
 __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint32_t n, int sh_degree,
                                                             const float4* __restrict__ density12,
                                                             const uint32_t* __restrict__ tiles_count,
@@ -597,6 +601,16 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
         const float dr = g2.w, dg = g3.x, db = g3.y;
         g2.w = 0.0f;
         const float4 a = density12[3 * (size_t)i];
+        if (kRawGrads) {
+            const float4 qn = density12[3 * (size_t)i + 1];
+            const float4 sc = density12[3 * (size_t)i + 2];
+            g0.w = g0.w * a.w * (1.0f - a.w);                                   // sigmoid'
+            const float dot = g1.x * qn.x + g1.y * qn.y + g1.z * qn.z + g1.w * qn.w;
+            const float inv = 1.0f / sc.w;                                      // 1/|quat_raw|
+            g1 = make_float4((g1.x - qn.x * dot) * inv, (g1.y - qn.y * dot) * inv, (g1.z - qn.z * dot) * inv,
+                             (g1.w - qn.w * dot) * inv);                        // normalise'
+            g2.x *= sc.x; g2.y *= sc.y; g2.z *= sc.z;                           // exp'
+        }
         const float rx = a.x - v.s2w.t[0], ry = a.y - v.s2w.t[1], rz = a.z - v.s2w.t[2];
         const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
         const float inv_dist = 1.0f / dist;
@@ -690,9 +704,10 @@ void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, 
 
 void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
                         const uint32_t* tiles_count, const float* feat, const float* grad16, float* density_grad12,
-                        float* sph_grad48) {
+                        float* sph_grad48, bool raw_grads) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_project_backward, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, n, sh_degree,
+    auto kern = raw_grads ? k_project_backward<true> : k_project_backward<false>;
+    hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), tiles_count, feat,
                        reinterpret_cast<const float4*>(grad16), reinterpret_cast<float4*>(density_grad12),
                        reinterpret_cast<float4*>(sph_grad48));

@@ -1,0 +1,163 @@
+"""Native train step: the same iteration as train.TrainStep (render -> 0.8*L1+0.2*(1-SSIM) -> backward -> [all-reduce]
+-> Adam with the reference's learning rates), but with the Gaussian-sized work kept out of torch autograd:
+
+    raw [N,12] --k_activate_pack--> activated [N,12] ----\
+    SH  [N,48] (one tensor, no cat) ----------------------> SplatRaster.trace            (HIP)
+    image-sized loss + its gradient: torch autograd on [H,W,*] tensors only (+ HIP fused SSIM)
+    SplatRaster.trace_bwd(raw_parameter_grads=True) -> dRaw [N,12], dSH [N,48]            (HIP; activation chain fused
+                                                                                           into the per-Gaussian epilogue)
+    [RCCL all-reduce of the two gradient tensors]
+    gut_adam_step on raw [N,12] and SH [N,48] with per-column learning rates              (HIP)
+
+This removes the ~20 Gaussian-sized elementwise/cat/split passes torch makes per step in the autograd path.
+The math is the same: tests compare one step of both paths (tests/test_gpu_native.py).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _capi
+from .losses import photometric_loss
+from .tracer import SplatRaster, Tracer
+
+# column layout of the raw [N,12] tensor and the reference's Adam learning rates (configs/base_gs.yaml:81-109)
+RAW_COLS = dict(positions=slice(0, 3), density=slice(3, 4), rotation=slice(4, 8), scale=slice(8, 11))
+
+
+class NativeGaussianModel:
+    """Parameters in the tracer's own layouts.  Exposes the reference's getter contract so that
+    Tracer.render(model, batch) works for evaluation."""
+
+    def __init__(self, scene: dict, device="cuda", sh_degree=3, background_color="black"):
+        n = scene["positions"].shape[0]
+        dens = np.clip(np.asarray(scene["density"], np.float64), 1e-6, 1 - 1e-6)
+        raw = np.zeros((n, 12), np.float32)
+        raw[:, 0:3] = scene["positions"]
+        raw[:, 3:4] = np.log(dens / (1 - dens))
+        raw[:, 4:8] = scene["rotation"]
+        raw[:, 8:11] = np.log(np.asarray(scene["scale"], np.float64))
+        self.raw = torch.as_tensor(raw, device=device)
+        self.features = torch.as_tensor(np.ascontiguousarray(scene["features"], np.float32), device=device)
+        self.n_active_features = int(sh_degree)
+        self.max_n_features = 3
+        self.background_color = background_color
+        self.device = device
+
+    @property
+    def num_gaussians(self):
+        return self.raw.shape[0]
+
+    @property
+    def positions(self):
+        return self.raw[:, 0:3]
+
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self.raw[:, 4:8], dim=1)
+
+    def get_scale(self):
+        return torch.exp(self.raw[:, 8:11])
+
+    def get_density(self):
+        return torch.sigmoid(self.raw[:, 3:4])
+
+    def get_features(self):
+        return self.features
+
+    def background(self, T_to_world, rays_d, rgb, opacity, train=False):
+        if self.background_color == "white":
+            rgb = rgb + (1.0 - opacity)
+        elif self.background_color == "random" and train:
+            rgb = rgb + torch.rand_like(rays_d) * (1.0 - opacity)
+        return rgb, opacity
+
+
+class NativeTrainStep:
+    def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
+                 betas=(0.9, 0.999), eps=1e-15):
+        self.model = model
+        self.tracer = tracer
+        self.raster: SplatRaster = tracer.tracer_wrapper
+        self.world_size = world_size
+        self.selective = selective
+        self.betas, self.eps = betas, eps
+        self._lib = _capi.load()
+        dev = model.raw.device
+        n = model.num_gaussians
+        lr12 = np.zeros(12, np.float32)
+        lr12[0:3] = 1.6e-4 * scene_extent   # positions
+        lr12[3] = 0.05                      # density
+        lr12[4:8] = 0.001                   # rotation
+        lr12[8:11] = 0.005                  # scale
+        lr48 = np.full(48, 0.000125, np.float32)  # specular
+        lr48[0:3] = 0.0025                  # albedo
+        self.lr12, self.lr48 = lr12, lr48
+        z = lambda c: torch.zeros((n, c), dtype=torch.float32, device=dev)
+        self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
+        self.act = torch.empty((n, 12), dtype=torch.float32, device=dev)
+        self.g12 = torch.empty((n, 12), dtype=torch.float32, device=dev)
+        self.g48 = torch.empty((n, 48), dtype=torch.float32, device=dev)
+        self.step_id = 0
+
+    # ---- pieces ----
+    def activate(self):
+        st = torch.cuda.current_stream(self.model.raw.device).cuda_stream
+        rc = self._lib.gut_activate_pack(C.c_void_p(st), self.model.num_gaussians, self.model.raw.data_ptr(), self.act.data_ptr())
+        if rc:
+            raise RuntimeError(f"[3dgut] activate_pack failed ({rc})")
+        return self.act
+
+    def _adam(self, p, g, m, v, lr, vis):
+        st = torch.cuda.current_stream(p.device).cuda_stream
+        lr_arr = (C.c_float * len(lr))(*[float(x) for x in lr])
+        rc = self._lib.gut_adam_step(C.c_void_p(st), p.shape[0], p.shape[1], p.data_ptr(), g.data_ptr(), m.data_ptr(),
+                                     v.data_ptr(), lr_arr, self.betas[0], self.betas[1], self.eps,
+                                     0 if self.selective else self.step_id + 1,
+                                     None if vis is None else vis.data_ptr())
+        if rc:
+            raise RuntimeError(f"[3dgut] adam_step failed ({rc})")
+
+    def forward(self, batch, train=True):
+        """Returns (pred_rgb [1,H,W,3] leaf requiring grad, pred_opacity, aux) without involving Gaussian-sized autograd."""
+        m = self.model
+        act = self.activate()
+        sensor, poses = Tracer.create_camera_parameters(batch)
+        rgba, dist_, hits, vis = self.raster.trace(self.step_id, m.n_active_features, act, m.features, batch.rays_ori.contiguous(),
+                                                  batch.rays_dir.contiguous(), None, sensor, poses.timestamps_us[0],
+                                                  poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1])
+        self._ctx = (batch, sensor, poses, rgba, dist_)
+        return rgba, dist_, hits, vis
+
+    def step(self, batch):
+        m = self.model
+        rgba, dist_, hits, vis = self.forward(batch)
+        rgba_leaf = rgba.detach().requires_grad_(True)
+        pred_rgb = rgba_leaf[..., :3].unsqueeze(0)
+        pred_opacity = rgba_leaf[..., 3:].unsqueeze(0)
+        pred_rgb, pred_opacity = m.background(batch.T_to_world, batch.rays_dir, pred_rgb, pred_opacity, True)
+        loss = photometric_loss(pred_rgb, batch.rgb_gt)
+        loss.backward()  # image-sized autograd only
+        _, sensor, poses, _, _ = self._ctx
+        self.raster.trace_bwd(self.step_id, m.n_active_features, self.act, m.features, batch.rays_ori.contiguous(),
+                              batch.rays_dir.contiguous(), None, sensor, poses.timestamps_us[0], poses.timestamps_us[1],
+                              poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_leaf.grad, dist_, None,
+                              raw_parameter_grads=True, out=(self.g12, self.g48))
+        if self.world_size > 1:
+            w1 = dist.all_reduce(self.g48, op=dist.ReduceOp.SUM, async_op=True)
+            w2 = dist.all_reduce(self.g12, op=dist.ReduceOp.SUM, async_op=True)
+            w3 = dist.all_reduce(vis, op=dist.ReduceOp.MAX, async_op=True) if self.selective else None
+            w1.wait(); w2.wait()
+            if w3 is not None:
+                w3.wait()
+            inv = 1.0 / self.world_size
+            self.g48.mul_(inv); self.g12.mul_(inv)
+        vmask = vis.reshape(-1) if self.selective else None
+        self._adam(m.raw, self.g12, self.m12, self.v12, self.lr12, vmask)
+        self._adam(m.features, self.g48, self.m48, self.v48, self.lr48, vmask)
+        self.step_id += 1
+        return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
+
+    def render(self, batch, train=False):
+        return self.tracer.render(self.model, batch, train=train, frame_id=self.step_id)

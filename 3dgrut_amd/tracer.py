@@ -203,7 +203,7 @@ class SplatRaster:
 
     def trace_bwd(self, frame_number, num_active_features, particle_density, particle_radiance, ray_ori, ray_dir, ray_time,
                   sensor_params, ts_start, ts_end, pose_start, pose_end, ray_radiance_density, ray_radiance_density_grd,
-                  ray_hit_distance, ray_hit_distance_grd):
+                  ray_hit_distance, ray_hit_distance_grd, raw_parameter_grads=False, out=None):
         ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
         ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
         H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
@@ -214,21 +214,25 @@ class SplatRaster:
         dist = _check_f32_cuda(ray_hit_distance, "rayHitDistance")
         dist_g = None if ray_hit_distance_grd is None else _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
         opts = dict(dtype=torch.float32, device=dev)
-        dens_g = torch.empty((n, 12), **opts)  # fully written by the per-Gaussian epilogue kernel
-        sph_g = torch.empty((n, 48), **opts)
+        if out is not None:
+            dens_g, sph_g = out
+        else:
+            dens_g = torch.empty((n, 12), **opts)  # fully written by the per-Gaussian epilogue kernel
+            sph_g = torch.empty((n, 48), **opts)
         if n:
             particle_density = _check_f32_cuda(particle_density, "particleDensity", (12,))
             particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
         cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = self._lib.gut_trace_bwd(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF,
+            rc = self._lib.gut_trace_bwd_ex(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF,
                                          int(num_active_features), n,
                                          particle_density.data_ptr() if n else None,
                                          particle_radiance.data_ptr() if n else None, W, H, ray_ori.data_ptr(),
                                          ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(), rgba_g.data_ptr(),
                                          dist.data_ptr(), None if dist_g is None else dist_g.data_ptr(), dens_g.data_ptr() if n else None,
-                                         sph_g.data_ptr() if n else None)
+                                         sph_g.data_ptr() if n else None,
+                                         _capi.BWD_RAW_PARAMETER_GRADS if raw_parameter_grads else 0)
         _capi.check(rc, "trace_bwd")
         return dens_g, sph_g
 

@@ -141,6 +141,19 @@ int gut_trace_bwd(gut_handle h, void* stream, uint32_t frame_number, int32_t num
                   const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad,
                   float* d_particle_density_grad, float* d_particle_radiance_grad);
 
+/* Same as gut_trace_bwd with option flags.  GUT_BWD_RAW_PARAMETER_GRADS: d_particle_density must be rows produced by
+ * gut_activate_pack (|quat| in the pad column); the [N,12] output is then the gradient w.r.t. the RAW parameters
+ * (density logit, un-normalised quaternion, log-scale), i.e. chained through sigmoid / normalise / exp
+ * (threedgrut/model/model.py:74-93), ready for gut_adam_step. */
+#define GUT_BWD_RAW_PARAMETER_GRADS 1u
+int gut_trace_bwd_ex(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features,
+                     uint32_t num_particles, const float* d_particle_density, const float* d_particle_radiance,
+                     int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
+                     const GutCamera* camera,
+                     const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                     const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad,
+                     float* d_particle_density_grad, float* d_particle_radiance_grad, uint32_t flags);
+
 /* SplatRaster::collectTimes — splatRaster.cpp:334-364: mean ms per tag over the timers recorded
  * since the last call; -1 for a tag with no samples. */
 int gut_collect_times(gut_handle h, float* forward_render_ms, float* backward_render_ms);
@@ -173,6 +186,18 @@ int gut_ssim_forward(void* stream, int32_t channels, int32_t height, int32_t wid
 int gut_ssim_backward(void* stream, int32_t channels, int32_t height, int32_t width, int64_t stride_c, int64_t stride_h,
                       int64_t stride_w, const float* d_img1, const float* d_img2, const void* d_workspace,
                       const float* d_upstream, float* d_grad_img1);
+
+/* ---- "next" row N2: parameter activation + fused Adam ----
+ * gut_activate_pack: raw rows [N,12] (pos3, density logit, quat4, log-scale3, unused) -> activated rows
+ *   (pos3, sigmoid, quat/|quat|, exp, |quat|) = the particle_density the tracer consumes (model.py:74-93 +
+ *   tracer.py:176-178 in one pass).
+ * gut_adam_step: in-place Adam on an [rows, cols] fp32 tensor, cols a multiple of 4 and <= 64, per-column learning
+ *   rates (host array).  step >= 1: torch.optim.Adam bias correction; step == 0: none (the reference's SelectiveAdam,
+ *   optimizers.cu:47-79).  d_visibility != NULL: rows with visibility == 0 are skipped entirely. */
+int gut_activate_pack(void* stream, uint32_t num_particles, const float* d_raw12, float* d_act12);
+int gut_adam_step(void* stream, uint64_t rows, uint32_t cols, float* d_param, const float* d_grad, float* d_exp_avg,
+                  float* d_exp_avg_sq, const float* lr_per_col, float beta1, float beta2, float eps, uint32_t step,
+                  const float* d_visibility);
 
 const char* gut_last_error(void);
 int gut_abi_version(void);
