@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--num-gaussians", type=int, default=0, help="override N (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--render-frames", type=int, default=10)
+    ap.add_argument("--trainer", default="native", choices=["native", "autograd"],
+                    help="native: fused HIP activation/Adam around the renderer; autograd: torch.autograd + torch.optim.Adam")
+    ap.add_argument("--selective-adam", action="store_true", help="visibility-masked Adam (reference SelectiveAdam)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,9 +147,14 @@ def main():
         kw["n"] = args.num_gaussians
     scene = getattr(scenes, fn)(**kw)  # same seed on every rank -> identical replicas
     sh_degree = 3
-    model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
     tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
-    stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
+    if args.trainer == "native":
+        native_mod = importlib.import_module("3dgrut_amd.native")
+        model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree)
+        stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam)
+    else:
+        model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
+        stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
 
     n_views = max(8, world)
     ro, rd, c2ws = make_views(cams, n_views, W, H, fx, radius, elev)
@@ -212,7 +220,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "num_gaussians": int(stats["num_particles"]), "resolution": [W, H],
                        "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}",
-                       "loss": "0.8*L1+0.2*(1-SSIM) (torch SSIM stand-in)", "optimizer": "Adam(fused), all 59 params/Gaussian"},
+                       "loss": "0.8*L1+0.2*(1-SSIM) (HIP fused SSIM)",
+                       "optimizer": ("HIP fused Adam" if args.trainer == "native" else "torch.optim.Adam(fused)") +
+                                    (" selective(visibility)" if args.selective_adam else "") + ", all 59 params/Gaussian",
+                       "trainer": args.trainer},
             "render_ms_per_frame": render_ms,
             "forward_render_ms_in_train": fb.get("forward_render"), "backward_render_ms_in_train": fb.get("backward_render"),
             "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
