@@ -17,9 +17,9 @@ import math
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from . import _capi
+from .dp import allreduce_max_, allreduce_mean_
 from .losses import photometric_loss
 from .tracer import SplatRaster, Tracer
 
@@ -145,14 +145,9 @@ class NativeTrainStep:
                               poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_leaf.grad, dist_, None,
                               raw_parameter_grads=True, out=(self.g12, self.g48))
         if self.world_size > 1:
-            w1 = dist.all_reduce(self.g48, op=dist.ReduceOp.SUM, async_op=True)
-            w2 = dist.all_reduce(self.g12, op=dist.ReduceOp.SUM, async_op=True)
-            w3 = dist.all_reduce(vis, op=dist.ReduceOp.MAX, async_op=True) if self.selective else None
-            w1.wait(); w2.wait()
-            if w3 is not None:
-                w3.wait()
-            inv = 1.0 / self.world_size
-            self.g48.mul_(inv); self.g12.mul_(inv)
+            allreduce_mean_([self.g48, self.g12], self.world_size)
+            if self.selective:
+                allreduce_max_(vis, self.world_size)
         vmask = vis.reshape(-1) if self.selective else None
         self._adam(m.raw, self.g12, self.m12, self.v12, self.lr12, vmask)
         self._adam(m.features, self.g48, self.m48, self.v48, self.lr48, vmask)

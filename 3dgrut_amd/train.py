@@ -16,9 +16,9 @@ step*world+r, gradients are summed with an RCCL all-reduce and divided by the wo
 import math
 
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 
+from .dp import allreduce_mean_
 from .losses import photometric_loss
 
 
@@ -83,15 +83,8 @@ class TrainStep:
         return loss, out
 
     def allreduce_gradients(self):
-        """SUM over ranks then divide: the loss of a step is the mean over the views of all ranks.
-        One collective per parameter tensor (6 large messages; SH is 81 % of the bytes), issued
-        back-to-back and awaited together so RCCL can pipeline them over the xGMI links."""
-        works = []
+        """SUM over ranks then divide: the loss of a step is the mean over the views of all ranks (dp.py)."""
         for p in self.model.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()
-        inv = 1.0 / self.world_size
-        torch._foreach_mul_([p.grad for p in self.model.parameters()], inv)
+        allreduce_mean_([p.grad for p in self.model.parameters()], self.world_size)

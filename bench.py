@@ -140,6 +140,7 @@ def main():
     pose_mod = importlib.import_module("3dgrut_amd.pose")
     model_mod = importlib.import_module("3dgrut_amd.model")
     train_mod = importlib.import_module("3dgrut_amd.train")
+    dp_mod = importlib.import_module("3dgrut_amd.dp")
 
     fn, kw, W, H, fx, radius, elev, extent = WORKLOADS[args.workload]
     kw = dict(kw)
@@ -166,7 +167,7 @@ def main():
     gt = (gt + 0.02 * torch.randn(gt.shape, generator=g)).clamp(0, 1)[None].to(dev)
 
     def batch_for(step):
-        v = (step * world + rank) % n_views
+        v = dp_mod.view_index(step, rank, world, n_views)
         return gut.Batch(rays_ori=ro_t, rays_dir=rd_t, T_to_world=torch.as_tensor(c2ws[v], device=dev)[None], rgb_gt=gt,
                          intrinsics_OpenCVPinholeCameraModelParameters=K)
 

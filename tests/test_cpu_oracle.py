@@ -1,0 +1,164 @@
+"""CPU tests of the oracle: known-answer tests, structural invariants, C oracle vs the independent float64
+PyTorch autograd restatement, and the host pose math against the golden vectors generated from the
+reference's own Python (tests/golden/gen_pose_golden.py)."""
+import importlib
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import cams, make_view, pose, scenes
+
+oracle = importlib.import_module("oracle.oracle")
+prt = importlib.import_module("oracle.per_ray_torch")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _single(pos, scale=0.1, dens=0.8, rgb0=(0.3, -0.2, 1.0)):
+    sc = dict(positions=np.array([pos], np.float32), rotation=np.array([[1, 0, 0, 0]], np.float32),
+              scale=np.full((1, 3), scale, np.float32), density=np.array([[dens]], np.float32),
+              features=np.zeros((1, 48), np.float32))
+    sc["features"][0, :3] = rgb0
+    return sc
+
+
+def test_pose_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "pose_golden.npz"))
+    for c2w, tq in zip(g["c2w"], g["tquat"]):
+        p = pose.sensor_pose_from_c2w(c2w)
+        assert p.timestamps_us == [0, 1]
+        assert np.abs(p.T_world_sensors[0] - tq).max() <= 1e-6
+        assert np.array_equal(p.T_world_sensors[0], p.T_world_sensors[1])
+
+
+def test_single_gaussian_on_axis_closed_form():
+    """alpha = min(.99, sigma*exp(-d^2/2)), rgb = max(0.28209479*c0+0.5, 0)*alpha, hitT = distance."""
+    W = H = 33
+    view = make_view("pinhole", W, H, np.eye(4, dtype=np.float32), fx=40.0)
+    sc = _single((0.0, 0.0, 3.0))
+    out = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=0)
+    assert out["tiles_count"][0] >= 1 and out["visibility"][0] == 1
+    c = out["rgba"][16, 16]
+    col = np.maximum(0.28209479177387814 * np.array([0.3, -0.2, 1.0]) + 0.5, 0)
+    assert abs(c[3] - 0.8) < 1e-6 and np.abs(c[:3] - col * 0.8).max() < 1e-6
+    assert abs(out["dist"][16, 16, 0] - 0.8 * 3.0) < 1e-5 and out["hits"][16, 16, 0] == 1
+    # off-axis pixel: response follows exp(-d^2/2) with d = perpendicular distance / scale
+    d = view["rd"][0, 16, 20]
+    perp = np.linalg.norm(np.cross(d, np.array([0, 0, 3.0]))) / 0.1
+    a = 0.8 * math.exp(-0.5 * perp * perp)
+    exp_a = a if (math.exp(-0.5 * perp * perp) > 0.0113 and a > 1 / 255) else 0.0
+    assert abs(out["rgba"][16, 20, 3] - exp_a) < 1e-5
+
+
+def test_front_to_back_order_and_saturation():
+    W = H = 17
+    view = make_view("pinhole", W, H, np.eye(4, dtype=np.float32), fx=30.0)
+    a, b = _single((0, 0, 2.0), dens=0.6, rgb0=(1.5, 1.5, 1.5)), _single((0, 0, 4.0), dens=0.9, rgb0=(-1.0, -1.0, -1.0))
+    sc = {k: np.concatenate([b[k], a[k]]) for k in a}  # far one first in memory: order must come from depth keys
+    out = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], sh_degree=0)
+    k = out["sorted_ids"][(out["sorted_keys"] >> np.uint64(32)) == 0]
+    assert list(k[:2]) == [1, 0]
+    ca = max(0.28209479177387814 * 1.5 + 0.5, 0); cb = max(0.28209479177387814 * -1.0 + 0.5, 0)
+    px = out["rgba"][8, 8]
+    assert abs(px[0] - (0.6 * ca + 0.4 * 0.9 * cb)) < 1e-6 and abs(px[3] - (1 - 0.4 * 0.1)) < 1e-6
+    # density 1.0 saturates at alpha 0.99
+    s = _single((0, 0, 2.0), dens=1.0)
+    o2 = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(s), s["features"], view["ro"], view["rd"], sh_degree=0)
+    assert abs(o2["rgba"][8, 8, 3] - 0.99) < 1e-6
+
+
+def test_culling_rules():
+    W = H = 32
+    view = make_view("pinhole", W, H, np.eye(4, dtype=np.float32), fx=30.0)
+    cases = {"low_opacity": _single((0, 0, 3.0), dens=1 / 255 - 1e-5), "behind_near": _single((0, 0, 0.19)),
+             "outside_margin": _single((30.0, 0, 3.0), scale=0.01), "ok": _single((0, 0, 3.0), dens=0.05)}
+    res = {k: oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(v), v["features"], view["ro"], view["rd"])["tiles_count"][0]
+           for k, v in cases.items()}
+    assert res["low_opacity"] == 0 and res["behind_near"] == 0 and res["outside_margin"] == 0 and res["ok"] >= 1
+
+
+def test_structural_invariants_and_pad_aliasing():
+    sc = scenes.scene_c1(600, 13)
+    W, H = 100, 70
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, 0.1, -3.0), (0, 0, 0)), fx=80.0)
+    o = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    T = 7 * 5
+    assert o["end_bit"] == 32 + 6 and oracle.higher_msb(T) == 6
+    for n in (1, 2, 3, 63, 64, 65, 2500, 4056, 65535, 65536):
+        assert oracle.higher_msb(n) == n.bit_length()
+    assert np.array_equal(np.cumsum(o["tiles_count"], dtype=np.uint32), o["tiles_offset"]) and o["M"] == int(o["tiles_count"].sum())
+    mask = (np.uint64(1) << np.uint64(o["end_bit"])) - np.uint64(1)
+    mk = o["sorted_keys"] & mask
+    assert np.all(mk[1:] >= mk[:-1])
+    # stability: equal keys keep emission (particle-index) order
+    same = mk[1:] == mk[:-1]
+    assert np.all(o["sorted_ids"][1:][same] > o["sorted_ids"][:-1][same])
+    tiles = (o["sorted_keys"] >> np.uint64(32)).astype(np.int64)
+    for t in range(T):
+        b, e = o["tile_ranges"][t]
+        assert np.all(tiles[b:e] == t) and (e - b) == int((tiles == t).sum())
+    # invalid keys (tile 0xFFFFFFFF) alias to 2^bw-1 >= T under the truncated sort and therefore sort last
+    keys = np.array([(3 << 32) | 5, (0xFFFFFFFF << 32) | 0x7F7FFFFF, (1 << 32) | 9], np.uint64)
+    ids = np.array([10, 0xFFFFFFFF, 11], np.uint32)
+    ko = np.zeros(3, np.uint64); io = np.zeros(3, np.uint32)
+    import ctypes as C
+    oracle.lib().oracle_sort_pairs(C.c_uint32(3), C.c_int(32 + 6), keys.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                   ko.ctypes.data_as(C.c_void_p), io.ctypes.data_as(C.c_void_p))
+    assert list(io) == [11, 10, 0xFFFFFFFF]
+    rng = np.zeros((T, 2), np.uint32)
+    oracle.lib().oracle_tile_ranges(C.c_uint32(3), C.c_uint32(T), ko.ctypes.data_as(C.c_void_p), rng.ctypes.data_as(C.c_void_p))
+    assert list(rng[1]) == [0, 1] and list(rng[3]) == [1, 2]
+
+
+def test_deterministic_log_and_atan():
+    L = oracle.lib()
+    xs = np.concatenate([np.geomspace(1e-30, 1e30, 400), np.linspace(0.5, 2.0, 300), [1.0, 255.0]]).astype(np.float32)
+    got = np.array([L.oracle_det_logf(float(x)) for x in xs])
+    assert np.abs(got - np.log(xs.astype(np.float64))).max() <= 3e-7 * np.maximum(1.0, np.abs(np.log(xs.astype(np.float64)))).max()
+    ys = np.geomspace(1e-6, 10, 60).astype(np.float32)
+    for y in ys:
+        for x in (-5.0, -0.3, 0.0, 0.2, 1.0, 7.0):
+            assert abs(L.oracle_det_atan2f(float(y), float(x)) - math.atan2(y, x)) <= 4e-7
+
+
+@pytest.mark.parametrize("kind", ["pinhole", "fisheye"])
+def test_c_oracle_matches_float64_autograd(kind):
+    sc = scenes.scene_c1(250, seed=5)
+    W, H = 48, 40
+    view = make_view(kind, W, H, cams.look_at_c2w((0.3, 0.2, -3.5 if kind == "pinhole" else -2.0), (0, 0, 0)), fx=50 if kind == "pinhole" else None)
+    f = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sc.items()}
+    rgba, dist, hits = prt.render_tiled(params, view["tq"], W, H, view["ro"], view["rd"], f["tile_ranges"], f["sorted_ids"])
+    assert np.abs(rgba.detach().numpy() - f["rgba"]).max() <= 2e-5
+    assert np.abs(hits.numpy() - f["hits"][..., 0]).max() == 0
+    rg = np.random.default_rng(0).normal(size=(H, W, 4)).astype(np.float32)
+    (rgba * torch.tensor(rg, dtype=torch.float64)).sum().backward()
+    dg, sg, _ = oracle.backward(view["oracle_cam"], f, rg, np.zeros((H, W, 1), np.float32))
+    rel = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+    assert rel(params["positions"].grad.numpy(), dg[:, 0:3]) <= 5e-5
+    assert rel(params["density"].grad.numpy()[:, 0], dg[:, 3]) <= 5e-5
+    assert rel(params["rotation"].grad.numpy(), dg[:, 4:8]) <= 5e-5
+    assert rel(params["scale"].grad.numpy(), dg[:, 8:11]) <= 5e-5
+    assert rel(params["features"].grad.numpy(), sg) <= 5e-5
+    # projection (K1) against the vectorised torch restatement
+    pr = prt.project(view["oracle_cam"], view["tq"], W, H, params)
+    assert np.array_equal(pr["valid"].numpy(), f["visibility"] > 0)
+    cnt = f["tiles_count"] > 0
+    assert np.abs(pr["center"].numpy()[cnt] - f["proj_pos"][cnt]).max() <= 5e-4
+    assert np.abs(pr["extent"].numpy()[cnt] - f["extent"][cnt]).max() <= 5e-4
+
+
+def test_golden_c1_fixture():
+    """Committed fixture of BASELINE configs[0] (1k Gaussians, 128x128): guards the oracle itself against drift."""
+    g = np.load(os.path.join(GOLD, "c1_golden.npz"))
+    sc = scenes.scene_c1(1000, 0)
+    view = make_view("pinhole", 128, 128, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=128.0)
+    o = oracle.forward(view["oracle_cam"], 128, 128, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    assert o["M"] == int(g["M"]) and np.array_equal(o["tiles_count"], g["tiles_count"])
+    assert np.array_equal(o["sorted_ids"], g["sorted_ids"]) and np.array_equal(o["sorted_keys"], g["sorted_keys"])
+    assert np.array_equal(o["tile_ranges"], g["tile_ranges"])
+    assert np.abs(o["rgba"][::4, ::4] - g["rgba_sub"]).max() <= 1e-6
+    dg, sg, _ = oracle.backward(view["oracle_cam"], o, g["rgba_grad"], np.zeros((128, 128, 1), np.float32))
+    assert np.abs(dg.sum(0) - g["density_grad_colsum"]).max() <= 1e-6 * max(1.0, np.abs(g["density_grad_colsum"]).max())
