@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  #
 GUT_ABI_VERSION = 1
 GUT_NUM_KERNEL_TIMERS = 8
 BWD_RAW_PARAMETER_GRADS = 1
+BWD_COMPACT_RADIANCE_GRADS = 2
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd")
 
 SHUTTER_GLOBAL = 4
@@ -56,7 +57,7 @@ class GutStats(C.Structure):
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
-           "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step")
+           "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step")
 
 _lib = None
 
@@ -98,6 +99,9 @@ def load():
     lib.gut_activate_pack.argtypes = [vp, u32, vp, vp]
     lib.gut_adam_step.argtypes = [vp, C.c_uint64, u32, vp, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float,
                                   C.c_float, u32, vp]
+    fptr = C.POINTER(C.c_float)
+    lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, fptr, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
+                                     C.c_float, C.c_float, C.c_float, u32, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
     _lib = lib

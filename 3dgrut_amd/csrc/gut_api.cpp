@@ -503,9 +503,13 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
                                h->trav_bwd.as<uint32_t>());
     mark(10);
-    gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
-                            h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad,
-                            (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0);
+    if (flags & GUT_BWD_COMPACT_RADIANCE_GRADS)
+        gut::launch_project_bwd_compact(s, n, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
+                                        h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad);
+    else
+        gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
+                                h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad,
+                                (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0);
     mark(11);
     HIP_TRY(hipGetLastError());
     if (total) {

@@ -636,6 +636,54 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
         sph_grad48[12 * (size_t)i + k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
 }
 
+// K8c: compact per-Gaussian epilogue for the fused optimiser / compact data-parallel exchange.  Writes the [N,12]
+// gradient chained to the RAW parameters and, instead of the [N,48] SH gradient, only its generator:
+// mrgb = dL/dRGB masked by (precomputed RGB > 0).  The SH gradient of a view is the rank-one product
+// Y_k(dir_view) * mrgb, which k_sh_adam rebuilds on the fly (per view) — 12 bytes per Gaussian and view cross the
+// wire instead of 192.
+__global__ __launch_bounds__(kBlock) void k_project_backward_compact(uint32_t n, const float4* __restrict__ density12,
+                                                                    const uint32_t* __restrict__ tiles_count,
+                                                                    const float* __restrict__ feat,
+                                                                    const float4* __restrict__ grad16,
+                                                                    float4* __restrict__ raw_grad12, float* __restrict__ mrgb) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    if (tiles_count[i] != 0) {
+        g0 = grad16[4 * (size_t)i + 0];
+        g1 = grad16[4 * (size_t)i + 1];
+        g2 = grad16[4 * (size_t)i + 2];
+        const float4 g3 = grad16[4 * (size_t)i + 3];
+        m0 = feat[3 * (size_t)i + 0] > 0.0f ? g2.w : 0.0f;
+        m1 = feat[3 * (size_t)i + 1] > 0.0f ? g3.x : 0.0f;
+        m2 = feat[3 * (size_t)i + 2] > 0.0f ? g3.y : 0.0f;
+        g2.w = 0.0f;
+        const float4 a = density12[3 * (size_t)i];
+        const float4 qn = density12[3 * (size_t)i + 1];
+        const float4 sc = density12[3 * (size_t)i + 2];
+        g0.w = g0.w * a.w * (1.0f - a.w);
+        const float dot = g1.x * qn.x + g1.y * qn.y + g1.z * qn.z + g1.w * qn.w;
+        const float inv = 1.0f / sc.w;
+        g1 = make_float4((g1.x - qn.x * dot) * inv, (g1.y - qn.y * dot) * inv, (g1.z - qn.z * dot) * inv, (g1.w - qn.w * dot) * inv);
+        g2.x *= sc.x; g2.y *= sc.y; g2.z *= sc.z;
+    }
+    raw_grad12[3 * (size_t)i + 0] = g0;
+    raw_grad12[3 * (size_t)i + 1] = g1;
+    raw_grad12[3 * (size_t)i + 2] = g2;
+    mrgb[3 * (size_t)i + 0] = m0;
+    mrgb[3 * (size_t)i + 1] = m1;
+    mrgb[3 * (size_t)i + 2] = m2;
+}
+
+void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density12, const uint32_t* tiles_count, const float* feat,
+                                const float* grad16, float* raw_grad12, float* mrgb) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_project_backward_compact, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n,
+                       reinterpret_cast<const float4*>(density12), tiles_count, feat, reinterpret_cast<const float4*>(grad16),
+                       reinterpret_cast<float4*>(raw_grad12), mrgb);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // statistics on demand (gut_get_stats): V = #{tiles_count > 0}, E_f / E_b = sums of the per-tile traversal depths
 // ---------------------------------------------------------------------------------------------------

@@ -53,7 +53,9 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 
 struct RayState {
     float ox, oy, oz, dx, dy, dz, tmin, tmax;
+    float ex, ey, ez;  // ray origin minus the sensor position (all zero for pinhole / fisheye rays)
     bool valid;
+    bool centred;      // the camera-space ray origin is exactly (0,0,0)
 };
 
 // camera-space ray -> world, slab test against the +-1e6 scene box (rayPayload.cuh:76-108,
@@ -62,7 +64,9 @@ __device__ __forceinline__ RayState make_ray(const ViewParams& v, const float* _
                                              const float* __restrict__ ray_dir, size_t pix, bool inside) {
     RayState r;
     r.valid = false;
+    r.centred = true;
     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.f;
+    r.ex = r.ey = r.ez = 0.f;
     r.tmin = 0.f;
     r.tmax = 0.f;
     if (!inside) return r;
@@ -75,6 +79,10 @@ __device__ __forceinline__ RayState make_ray(const ViewParams& v, const float* _
     r.dx = m.r[0][0] * b0 + m.r[0][1] * b1 + m.r[0][2] * b2;
     r.dy = m.r[1][0] * b0 + m.r[1][1] * b1 + m.r[1][2] * b2;
     r.dz = m.r[2][0] * b0 + m.r[2][1] * b1 + m.r[2][2] * b2;
+    r.centred = (a0 == 0.0f) && (a1 == 0.0f) && (a2 == 0.0f);
+    r.ex = m.r[0][0] * a0 + m.r[0][1] * a1 + m.r[0][2] * a2;
+    r.ey = m.r[1][0] * a0 + m.r[1][1] * a1 + m.r[1][2] * a2;
+    r.ez = m.r[2][0] * a0 + m.r[2][1] * a1 + m.r[2][2] * a2;
     const float lo = -1e06f, hi = 1e06f, fmx = 3.4028235e+38f;
     float tmin = (lo - r.ox) / r.dx, tmax = (hi - r.ox) / r.dx;
     if (tmin > tmax) { const float t = tmin; tmin = tmax; tmax = t; }
@@ -108,8 +116,12 @@ __device__ __forceinline__ void quat_rows(float w, float x, float y, float z, fl
 // ---------------------------------------------------------------------------------------------------
 // K6 forward
 // ---------------------------------------------------------------------------------------------------
+// Canonical-space ray origin:  o = M (ray_o - mu) = M (sensor_pos - mu) + M (ray_o - sensor_pos) = oc + M e.
+// oc is a per-entry constant computed once at staging; e is a per-pixel constant that is exactly zero for every
+// camera the reference has (rays start at the sensor position), in which case the whole tile skips the M e term
+// (block-uniform flag) and the per-pair work is one 3x3 mat-vec instead of two.
 struct FwdEntry {      // 80 bytes, 16-byte aligned: five ds_read_b128 broadcasts per entry
-    float4 mu_sigma;   // mean.xyz, density
+    float4 mu_sigma;   // oc = M (sensor_pos - mean), density
     float4 m0;         // row 0 of M = diag(1/s) * rotationT, s.x
     float4 m1;         // row 1, s.y
     float4 m2;         // row 2, s.z
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                                                   float4* __restrict__ rgba, float* __restrict__ dist,
                                                   float* __restrict__ hits, uint32_t* __restrict__ tile_traversed) {
     __shared__ FwdEntry stage[kBlock];
-    __shared__ uint32_t s_deepest;
+    __shared__ uint32_t s_deepest, s_first_invalid;
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -135,7 +147,11 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
     // (gutRenderer.cu:323-325); treating every ray as invalid writes exactly those
     const RayState ray = make_ray(v, ray_ori, ray_dir, pix, inside && (num_intersections != 0));
 
-    if (tid == 0) s_deepest = 0;
+    if (tid == 0) {
+        s_deepest = 0;
+        s_first_invalid = kBlock;
+    }
+    const bool centred = __syncthreads_and(ray.centred ? 1 : 0) != 0;  // block-uniform
 
     const uint2 range = ranges[tile];
     const uint32_t total = range.y - range.x;
@@ -158,54 +174,59 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                 float r[3][3];
                 quat_rows(q.x, q.y, q.z, q.w, r);
                 const float i0 = 1.0f / s.x, i1 = 1.0f / s.y, i2 = 1.0f / s.z;
-                e.mu_sigma = a;
                 e.m0 = make_float4(r[0][0] * i0, r[0][1] * i0, r[0][2] * i0, s.x);
                 e.m1 = make_float4(r[1][0] * i1, r[1][1] * i1, r[1][2] * i1, s.y);
                 e.m2 = make_float4(r[2][0] * i2, r[2][1] * i2, r[2][2] * i2, s.z);
+                const float c0 = v.s2w.t[0] - a.x, c1 = v.s2w.t[1] - a.y, c2 = v.s2w.t[2] - a.z;
+                e.mu_sigma = make_float4(e.m0.x * c0 + e.m0.y * c1 + e.m0.z * c2, e.m1.x * c0 + e.m1.y * c1 + e.m1.z * c2,
+                                         e.m2.x * c0 + e.m2.y * c1 + e.m2.z * c2, a.w);
                 e.feat_id.x = fmaxf(feat[3 * (size_t)id + 0], 0.0f);
                 e.feat_id.y = fmaxf(feat[3 * (size_t)id + 1], 0.0f);
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
             }
             stage[tid] = e;
+            if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
         }
         __syncthreads();
 
-        const uint32_t cnt = min((uint32_t)kBlock, total - base);
+        // entries of this chunk that are real particles (padding ids end the list for everyone, gutKBufferRenderer.cuh:256-259)
+        const uint32_t cnt = min(min((uint32_t)kBlock, total - base), s_first_invalid);
+        // software pipeline: the parameters of entry j+1 are fetched from LDS while entry j is evaluated
+        float4 ms = stage[0].mu_sigma, m0 = stage[0].m0, m1 = stage[0].m1, m2 = stage[0].m2;
         for (uint32_t j = 0; j < cnt; ++j) {
             if (__ballot(alive) == 0ull) break;  // wave-uniform
-            const float4 fid = stage[j].feat_id;
-            if (__float_as_uint(fid.w) == kInvalid) {  // padding entry: list ends here for everyone
-                alive = false;
-                break;
-            }
+            const float4 cs = ms, c0 = m0, c1 = m1, c2 = m2;
+            const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
+            ms = stage[jn].mu_sigma; m0 = stage[jn].m0; m1 = stage[jn].m1; m2 = stage[jn].m2;
             if (alive) {
                 consumed = base + j + 1;
-                const float4 ms = stage[j].mu_sigma;
-                const float4 m0 = stage[j].m0, m1 = stage[j].m1, m2 = stage[j].m2;
-                const float gx = ray.ox - ms.x, gy = ray.oy - ms.y, gz = ray.oz - ms.z;
-                const float o0 = m0.x * gx + m0.y * gy + m0.z * gz;
-                const float o1 = m1.x * gx + m1.y * gy + m1.z * gz;
-                const float o2 = m2.x * gx + m2.y * gy + m2.z * gz;
-                const float u0 = m0.x * ray.dx + m0.y * ray.dy + m0.z * ray.dz;
-                const float u1 = m1.x * ray.dx + m1.y * ray.dy + m1.z * ray.dz;
-                const float u2 = m2.x * ray.dx + m2.y * ray.dy + m2.z * ray.dz;
-                const float c0 = u1 * o2 - u2 * o1, c1 = u2 * o0 - u0 * o2, c2 = u0 * o1 - u1 * o0;
+                float o0 = cs.x, o1 = cs.y, o2 = cs.z;
+                if (!centred) {
+                    o0 += c0.x * ray.ex + c0.y * ray.ey + c0.z * ray.ez;
+                    o1 += c1.x * ray.ex + c1.y * ray.ey + c1.z * ray.ez;
+                    o2 += c2.x * ray.ex + c2.y * ray.ey + c2.z * ray.ez;
+                }
+                const float u0 = c0.x * ray.dx + c0.y * ray.dy + c0.z * ray.dz;
+                const float u1 = c1.x * ray.dx + c1.y * ray.dy + c1.z * ray.dz;
+                const float u2 = c2.x * ray.dx + c2.y * ray.dy + c2.z * ray.dz;
+                const float x0 = u1 * o2 - u2 * o1, x1 = u2 * o0 - u0 * o2, x2 = u0 * o1 - u1 * o0;
                 const float l2 = u0 * u0 + u1 * u1 + u2 * u2;
                 const float il2 = fast_rcp(l2);
-                const float d2 = (c0 * c0 + c1 * c1 + c2 * c2) * il2;  // |grd x gro|^2 with grd = u/|u|
+                const float d2 = (x0 * x0 + x1 * x1 + x2 * x2) * il2;  // |grd x gro|^2 with grd = u/|u|
                 if (d2 < c.max_d2) {
                     const float resp = fast_exp(-0.5f * d2);
-                    const float alpha = fminf(c.max_alpha, resp * ms.w);
+                    const float alpha = fminf(c.max_alpha, resp * cs.w);
                     if ((resp > c.min_response) && (alpha > c.alpha_threshold)) {
                         // hitT = | s * grd * (grd . -gro) |
                         const float proj = -(u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (grd.-gro)/|u|
-                        const float h0 = m0.w * u0 * proj, h1 = m1.w * u1 * proj, h2 = m2.w * u2 * proj;
+                        const float h0 = c0.w * u0 * proj, h1 = c1.w * u1 * proj, h2 = c2.w * u2 * proj;
                         const float hit_t = sqrtf(h0 * h0 + h1 * h1 + h2 * h2);
                         if ((hit_t > ray.tmin) && (hit_t < ray.tmax)) {
                             const float w = alpha * T;
                             dsum += hit_t * w;
                             T *= (1.0f - alpha);
                             if (w > 0.0f) {
+                                const float4 fid = stage[j].feat_id;
                                 cr += fid.x * w;
                                 cg += fid.y * w;
                                 cb += fid.z * w;
@@ -217,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                 }
             }
         }
+        if (cnt < min((uint32_t)kBlock, total - base)) alive = false;  // list ended at a padding entry
     }
 
     if (inside) {
@@ -310,7 +332,7 @@ struct AccLayout {
 };
 
 template <bool kDistGrad>
-__global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, RenderConsts c,
+__global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, RenderConsts c,
                                                            const float4* __restrict__ density12,
                                                            const float* __restrict__ feat,
                                                            const float* __restrict__ ray_ori,
@@ -324,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
     constexpr int W = AccLayout<kDistGrad>::kW;
     __shared__ FwdEntry stage[kBlock];
     __shared__ float acc[kBlock * W];
-    __shared__ uint32_t s_deepest;
+    __shared__ uint32_t s_deepest, s_first_invalid;
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -335,7 +357,11 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
     const size_t pix = (size_t)py * (size_t)v.width + (size_t)px;
     const RayState ray = make_ray(v, ray_ori, ray_dir, pix, inside);
 
-    if (tid == 0) s_deepest = 0;
+    if (tid == 0) {
+        s_deepest = 0;
+        s_first_invalid = kBlock;
+    }
+    const bool centred = __syncthreads_and(ray.centred ? 1 : 0) != 0;  // block-uniform
 #pragma unroll
     for (int k = 0; k < W; ++k) acc[k * kBlock + tid] = 0.0f;
 
@@ -373,37 +399,41 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
                 float r[3][3];
                 quat_rows(q.x, q.y, q.z, q.w, r);
                 const float i0 = 1.0f / sc.x, i1 = 1.0f / sc.y, i2 = 1.0f / sc.z;
-                e.mu_sigma = a;
                 e.m0 = make_float4(r[0][0] * i0, r[0][1] * i0, r[0][2] * i0, sc.x);
                 e.m1 = make_float4(r[1][0] * i1, r[1][1] * i1, r[1][2] * i1, sc.y);
                 e.m2 = make_float4(r[2][0] * i2, r[2][1] * i2, r[2][2] * i2, sc.z);
+                const float c0 = v.s2w.t[0] - a.x, c1 = v.s2w.t[1] - a.y, c2 = v.s2w.t[2] - a.z;
+                e.mu_sigma = make_float4(e.m0.x * c0 + e.m0.y * c1 + e.m0.z * c2, e.m1.x * c0 + e.m1.y * c1 + e.m1.z * c2,
+                                         e.m2.x * c0 + e.m2.y * c1 + e.m2.z * c2, a.w);
                 e.feat_id.x = fmaxf(feat[3 * (size_t)id + 0], 0.0f);
                 e.feat_id.y = fmaxf(feat[3 * (size_t)id + 1], 0.0f);
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
             }
             stage[tid] = e;
+            if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
         }
         __syncthreads();
 
-        const uint32_t cnt = min((uint32_t)kBlock, total - base);
+        const uint32_t cnt_all = min((uint32_t)kBlock, total - base);
+        const uint32_t cnt = min(cnt_all, s_first_invalid);  // padding ids end the list for everyone
+        float4 nms = stage[0].mu_sigma, nm0 = stage[0].m0, nm1 = stage[0].m1, nm2 = stage[0].m2;
         for (uint32_t j = 0; j < cnt; ++j) {
             if (__ballot(alive) == 0ull) break;
-            const float4 fid = stage[j].feat_id;
-            if (__float_as_uint(fid.w) == kInvalid) {
-                alive = false;
-                break;
-            }
+            // software pipeline: entry j+1 is fetched from LDS while entry j is evaluated
+            const float4 ms = nms, m0 = nm0, m1 = nm1, m2 = nm2;
+            const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
+            nms = stage[jn].mu_sigma; nm0 = stage[jn].m0; nm1 = stage[jn].m1; nm2 = stage[jn].m2;
             float g[16];
             float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;  // direct scale terms (kDistGrad only)
             bool hit = false;
             if (alive) {
                 consumed = base + j + 1;
-                const float4 ms = stage[j].mu_sigma;
-                const float4 m0 = stage[j].m0, m1 = stage[j].m1, m2 = stage[j].m2;
-                const float p0 = ray.ox - ms.x, p1 = ray.oy - ms.y, p2 = ray.oz - ms.z;
-                const float o0 = m0.x * p0 + m0.y * p1 + m0.z * p2;
-                const float o1 = m1.x * p0 + m1.y * p1 + m1.z * p2;
-                const float o2 = m2.x * p0 + m2.y * p1 + m2.z * p2;
+                float o0 = ms.x, o1 = ms.y, o2 = ms.z;
+                if (!centred) {
+                    o0 += m0.x * ray.ex + m0.y * ray.ey + m0.z * ray.ez;
+                    o1 += m1.x * ray.ex + m1.y * ray.ey + m1.z * ray.ez;
+                    o2 += m2.x * ray.ex + m2.y * ray.ey + m2.z * ray.ez;
+                }
                 const float u0 = m0.x * ray.dx + m0.y * ray.dy + m0.z * ray.dz;
                 const float u1 = m1.x * ray.dx + m1.y * ray.dy + m1.z * ray.dz;
                 const float u2 = m2.x * ray.dx + m2.y * ray.dy + m2.z * ray.dz;
@@ -417,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
                     const float alpha = fminf(c.max_alpha, a0);
                     if ((resp > c.min_response) && (alpha > c.alpha_threshold)) {  // NB: no tmin/tmax test in the backward
                         hit = true;
+                        const float4 fid = stage[j].feat_id;
                         const float w = alpha * T;
                         const float Tn = (1.0f - alpha) * T;
                         const float t = (u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (u.o)/|u|^2
@@ -454,7 +485,9 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
                         const float g_d2x2 = -a0 * G;          // 2 * dL/d(d2) = 2 * (-1/2 resp sigma G)
                         float h0 = g_d2x2 * q0, h1 = g_d2x2 * q1, h2 = g_d2x2 * q2;  // dL/do
                         if (!kDistGrad) {
-                            const float n0 = p0 - t * ray.dx, n1 = p1 - t * ray.dy, n2 = p2 - t * ray.dz;  // m
+                            // m = (ray_o - mu) - t d = (e - t d) + (sensor_pos - mu); the second, per-entry constant part is
+                            // added in the epilogue as H (x) (sensor_pos - mu)
+                            const float n0 = ray.ex - t * ray.dx, n1 = ray.ey - t * ray.dy, n2 = ray.ez - t * ray.dz;
                             g[0] = h0 * n0; g[1] = h0 * n1; g[2] = h0 * n2;
                             g[3] = h1 * n0; g[4] = h1 * n1; g[5] = h1 * n2;
                             g[6] = h2 * n0; g[7] = h2 * n1; g[8] = h2 * n2;
@@ -472,9 +505,9 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
                             v0 += il * (hd0 - d0 * dot);
                             v1 += il * (hd1 - d1 * dot);
                             v2 += il * (hd2 - d2n * dot);
-                            g[0] = h0 * p0 + v0 * ray.dx; g[1] = h0 * p1 + v0 * ray.dy; g[2] = h0 * p2 + v0 * ray.dz;
-                            g[3] = h1 * p0 + v1 * ray.dx; g[4] = h1 * p1 + v1 * ray.dy; g[5] = h1 * p2 + v1 * ray.dz;
-                            g[6] = h2 * p0 + v2 * ray.dx; g[7] = h2 * p1 + v2 * ray.dy; g[8] = h2 * p2 + v2 * ray.dz;
+                            g[0] = h0 * ray.ex + v0 * ray.dx; g[1] = h0 * ray.ey + v0 * ray.dy; g[2] = h0 * ray.ez + v0 * ray.dz;
+                            g[3] = h1 * ray.ex + v1 * ray.dx; g[4] = h1 * ray.ey + v1 * ray.dy; g[5] = h1 * ray.ez + v1 * ray.dz;
+                            g[6] = h2 * ray.ex + v2 * ray.dx; g[7] = h2 * ray.ey + v2 * ray.dy; g[8] = h2 * ray.ez + v2 * ray.dz;
                         }
                         g[9] = h0; g[10] = h1; g[11] = h2;
                         T = Tn;
@@ -500,6 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
             }
         }
 
+        if (cnt < cnt_all) alive = false;  // list ended at a padding entry
         // ---- chunk epilogue: (A, H) -> d(position), d(scale), d(quaternion), one entry per lane ----
         __syncthreads();
         if (tid < cnt) {
@@ -509,13 +543,17 @@ __global__ __launch_bounds__(kBlock) void k_render_backward(ViewParams v, Render
 #pragma unroll
             for (int k = 0; k < W; ++k) any = any || (a[k] != 0.0f);
             if (any && id != kInvalid) {
+                const float4 mu = density12[3 * (size_t)id + 0];
                 const float4 q = density12[3 * (size_t)id + 1];
                 const float4 sc = density12[3 * (size_t)id + 2];
                 float r[3][3];
                 quat_rows(q.x, q.y, q.z, q.w, r);
                 const float is[3] = {1.0f / sc.x, 1.0f / sc.y, 1.0f / sc.z};
-                const float A[3][3] = {{a[0], a[1], a[2]}, {a[3], a[4], a[5]}, {a[6], a[7], a[8]}};
                 const float H[3] = {a[9], a[10], a[11]};
+                const float pc[3] = {v.s2w.t[0] - mu.x, v.s2w.t[1] - mu.y, v.s2w.t[2] - mu.z};
+                const float A[3][3] = {{a[0] + H[0] * pc[0], a[1] + H[0] * pc[1], a[2] + H[0] * pc[2]},
+                                       {a[3] + H[1] * pc[0], a[4] + H[1] * pc[1], a[5] + H[1] * pc[2]},
+                                       {a[6] + H[2] * pc[0], a[7] + H[2] * pc[1], a[8] + H[2] * pc[2]}};
                 const float d_dens = a[12], d_r = a[13], d_g = a[14], d_b = a[15];
                 float out[16];
                 // d mu = -M^T H

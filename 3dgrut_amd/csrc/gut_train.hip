@@ -59,6 +59,133 @@ __global__ __launch_bounds__(kBlock) void k_adam_step(AdamParams ap, uint64_t n_
     v[idx] = vv;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_sh_adam: fused (multi-view) SH-gradient rebuild + Adam for both parameter tensors, one wave per 64 Gaussians.
+// The [N,48] SH gradient never exists in memory: each lane rebuilds its Gaussian's 48 gradient values from the
+// compact per-view rows (3 floats per view), drops them into a wave-private LDS tile (row stride 49 dwords), and
+// the wave then streams the contiguous 12 KiB blocks of p / m / v with fully coalesced 16-byte accesses, picking
+// the matching gradients out of LDS.  Traffic per Gaussian: 12 B x views + 48 (grad12) + 6 x 240 (p,m,v in/out).
+// ---------------------------------------------------------------------------------------------------
+struct ShAdamParams {
+    AdamParams a12, a48;
+    float cam[16][3];
+    uint32_t n, views;
+    int32_t sh_degree;
+    float grad_scale;
+};
+
+__device__ __forceinline__ void sh_basis_fast(int deg, float x, float y, float z, float Y[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Y[i] = 0.0f;
+    Y[0] = 0.28209479177387814f;
+    if (deg > 0) {
+        Y[1] = -0.4886025119029199f * y; Y[2] = 0.4886025119029199f * z; Y[3] = -0.4886025119029199f * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            Y[4] = 1.0925484305920792f * xy; Y[5] = -1.0925484305920792f * yz;
+            Y[6] = 0.31539156525252005f * (2.0f * zz - xx - yy); Y[7] = -1.0925484305920792f * xz;
+            Y[8] = 0.5462742152960396f * (xx - yy);
+            if (deg > 2) {
+                Y[9] = -0.5900435899266435f * y * (3.0f * xx - yy); Y[10] = 2.890611442640554f * xy * z;
+                Y[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+                Y[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                Y[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy); Y[14] = 1.445305721320277f * z * (xx - yy);
+                Y[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void adam4(const AdamParams& ap, uint32_t c0, const float4& g, float4& p, float4& m, float4& v) {
+#define GUT_ADAM_LANE(X, K)                               \
+    m.X = ap.beta1 * m.X + (1.0f - ap.beta1) * g.X;        \
+    v.X = ap.beta2 * v.X + (1.0f - ap.beta2) * g.X * g.X;  \
+    p.X -= (ap.lr[c0 + K] / ap.bias1) * m.X / (sqrtf(v.X) / ap.bias2_sqrt + ap.eps);
+    GUT_ADAM_LANE(x, 0)
+    GUT_ADAM_LANE(y, 1)
+    GUT_ADAM_LANE(z, 2)
+    GUT_ADAM_LANE(w, 3)
+#undef GUT_ADAM_LANE
+}
+
+__global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float* __restrict__ mrgb,
+                                                   const float4* __restrict__ grad12, float4* __restrict__ p12,
+                                                   float4* __restrict__ m12, float4* __restrict__ v12, float4* __restrict__ p48,
+                                                   float4* __restrict__ m48, float4* __restrict__ v48,
+                                                   const float* __restrict__ visibility) {
+    constexpr int kRow = 49;
+    __shared__ float tile[(kBlock / 64) * 64 * kRow];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* wl = tile + wave * 64 * kRow;
+    const uint32_t wave_first = blockIdx.x * kBlock + wave * 64u;
+    const uint32_t rows_here = wave_first < sp.n ? min(64u, sp.n - wave_first) : 0u;
+    float G[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) G[k] = 0.0f;
+    bool active = false;
+    if (i < sp.n) {
+        active = !(visibility && !(visibility[i] != 0.0f));
+        float4 a = p12[3 * (size_t)i + 0];
+        const float px = a.x, py = a.y, pz = a.z;  // pre-update position: the direction the forward used
+        if (active) {
+            // --- raw [N,12] row ---
+            float4 b = p12[3 * (size_t)i + 1], c = p12[3 * (size_t)i + 2];
+            float4 g0 = grad12[3 * (size_t)i + 0], g1 = grad12[3 * (size_t)i + 1], g2 = grad12[3 * (size_t)i + 2];
+            const float gs = sp.grad_scale;
+            g0.x *= gs; g0.y *= gs; g0.z *= gs; g0.w *= gs; g1.x *= gs; g1.y *= gs; g1.z *= gs; g1.w *= gs;
+            g2.x *= gs; g2.y *= gs; g2.z *= gs; g2.w = 0.0f;
+            float4 ma = m12[3 * (size_t)i + 0], mb = m12[3 * (size_t)i + 1], mc = m12[3 * (size_t)i + 2];
+            float4 va = v12[3 * (size_t)i + 0], vb = v12[3 * (size_t)i + 1], vc = v12[3 * (size_t)i + 2];
+            adam4(sp.a12, 0, g0, a, ma, va);
+            adam4(sp.a12, 4, g1, b, mb, vb);
+            adam4(sp.a12, 8, g2, c, mc, vc);
+            p12[3 * (size_t)i + 0] = a; p12[3 * (size_t)i + 1] = b; p12[3 * (size_t)i + 2] = c;
+            m12[3 * (size_t)i + 0] = ma; m12[3 * (size_t)i + 1] = mb; m12[3 * (size_t)i + 2] = mc;
+            v12[3 * (size_t)i + 0] = va; v12[3 * (size_t)i + 1] = vb; v12[3 * (size_t)i + 2] = vc;
+            // --- rebuild the SH gradient of this Gaussian from the compact per-view rows ---
+            for (uint32_t vw = 0; vw < sp.views; ++vw) {
+                const float* mr = mrgb + ((size_t)vw * sp.n + i) * 3;
+                const float r = mr[0] * sp.grad_scale, g = mr[1] * sp.grad_scale, bl = mr[2] * sp.grad_scale;
+                if (r == 0.0f && g == 0.0f && bl == 0.0f) continue;
+                const float dx = px - sp.cam[vw][0], dy = py - sp.cam[vw][1], dz = pz - sp.cam[vw][2];
+                const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                float Y[16];
+                sh_basis_fast(sp.sh_degree, dx * inv, dy * inv, dz * inv, Y);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    G[3 * k + 0] += Y[k] * r;
+                    G[3 * k + 1] += Y[k] * g;
+                    G[3 * k + 2] += Y[k] * bl;
+                }
+            }
+        }
+    }
+    // stage gradients + row-active flag (column 48) in the wave-private LDS tile
+#pragma unroll
+    for (int k = 0; k < 48; ++k) wl[lane * kRow + k] = G[k];
+    wl[lane * kRow + 48] = active ? 1.0f : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // coalesced sweep over the wave's contiguous [rows_here, 48] blocks of p, m, v
+    float4* bp = p48 + (size_t)wave_first * 12;
+    float4* bm = m48 + (size_t)wave_first * 12;
+    float4* bv = v48 + (size_t)wave_first * 12;
+#pragma unroll 4
+    for (int it = 0; it < 12; ++it) {
+        const uint32_t q = (uint32_t)it * 64u + lane;
+        if (q >= rows_here * 12u) continue;
+        const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
+        if (wl[row * kRow + 48] == 0.0f) continue;  // SelectiveAdam: untouched row
+        const float* gsrc = wl + row * kRow + col;
+        const float4 g = make_float4(gsrc[0], gsrc[1], gsrc[2], gsrc[3]);
+        float4 pp = bp[q], mm = bm[q], vv = bv[q];
+        adam4(sp.a48, col, g, pp, mm, vv);
+        bp[q] = pp; bm[q] = mm; bv[q] = vv;
+    }
+}
+
 }  // namespace gut
 
 extern "C" {
@@ -94,6 +221,40 @@ int gut_adam_step(void* stream, uint64_t rows, uint32_t cols, float* d_param, co
     hipLaunchKernelGGL(gut::k_adam_step, dim3((uint32_t)blocks), dim3(gut::kBlock), 0, static_cast<hipStream_t>(stream), ap, n_vec4,
                        reinterpret_cast<float4*>(d_param), reinterpret_cast<const float4*>(d_grad),
                        reinterpret_cast<float4*>(d_exp_avg), reinterpret_cast<float4*>(d_exp_avg_sq), d_visibility);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+static void fill_adam(gut::AdamParams& ap, const float* lr, uint32_t cols, float beta1, float beta2, float eps, uint32_t step) {
+    for (uint32_t i = 0; i < 64; ++i) ap.lr[i] = i < cols ? lr[i] : 0.0f;
+    ap.beta1 = beta1; ap.beta2 = beta2; ap.eps = eps; ap.cols = cols;
+    if (step) {
+        ap.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
+        ap.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    } else {
+        ap.bias1 = 1.0f; ap.bias2_sqrt = 1.0f;
+    }
+}
+
+int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* camera_positions,
+                     const float* d_mrgb, const float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
+                     float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                     float beta1, float beta2, float eps, uint32_t step, const float* d_visibility) {
+    if (num_particles == 0) return 0;
+    if (!camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
+        !lr12 || !lr48)
+        return 1;
+    if (num_views == 0 || num_views > 16 || sh_degree < 0 || sh_degree > 3) return 3;
+    gut::ShAdamParams sp;
+    fill_adam(sp.a12, lr12, 12, beta1, beta2, eps, step);
+    fill_adam(sp.a48, lr48, 48, beta1, beta2, eps, step);
+    for (uint32_t v = 0; v < 16; ++v)
+        for (int k = 0; k < 3; ++k) sp.cam[v][k] = v < num_views ? camera_positions[3 * v + k] : 0.0f;
+    sp.n = num_particles; sp.views = num_views; sp.sh_degree = sh_degree; sp.grad_scale = grad_scale;
+    hipLaunchKernelGGL(gut::k_sh_adam, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
+                       static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<const float4*>(d_raw_grad12),
+                       reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v),
+                       reinterpret_cast<float4*>(d_sh48), reinterpret_cast<float4*>(d_sh_m), reinterpret_cast<float4*>(d_sh_v),
+                       d_visibility);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -30,3 +30,18 @@ def allreduce_mean_(tensors, world: int, group=None):
 def allreduce_max_(tensor, world: int, group=None):
     if world > 1:
         dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group)
+
+
+def allgather_rows_(out, local, world: int, group=None):
+    """out[world, ...] <- every rank's `local` tensor (rank order).  out[rank] may alias local."""
+    if world <= 1:
+        if out[0].data_ptr() != local.data_ptr():
+            out[0].copy_(local)
+        return
+    try:
+        dist.all_gather_into_tensor(out, local, group=group)
+    except (RuntimeError, NotImplementedError):  # backends without the flat variant (gloo)
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+        for r, t in enumerate(parts):
+            out[r].copy_(t)

@@ -17,9 +17,10 @@ import math
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import _capi
-from .dp import allreduce_max_, allreduce_mean_
+from .dp import allgather_rows_, allreduce_max_, allreduce_mean_
 from .losses import photometric_loss
 from .tracer import SplatRaster, Tracer
 
@@ -76,7 +77,7 @@ class NativeGaussianModel:
 
 class NativeTrainStep:
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
-                 betas=(0.9, 0.999), eps=1e-15):
+                 betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0):
         self.model = model
         self.tracer = tracer
         self.raster: SplatRaster = tracer.tracer_wrapper
@@ -98,7 +99,16 @@ class NativeTrainStep:
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
         self.act = torch.empty((n, 12), dtype=torch.float32, device=dev)
         self.g12 = torch.empty((n, 12), dtype=torch.float32, device=dev)
-        self.g48 = torch.empty((n, 48), dtype=torch.float32, device=dev)
+        self.fused = bool(fused_sh_adam)
+        self.rank = int(rank)
+        if self.fused:
+            # compact exchange: per view only dL/dRGB (12 B per Gaussian) travels; the [N,48] SH gradient is rebuilt
+            # inside the fused SH-gradient + Adam kernel (csrc/gut_train.hip: k_sh_adam)
+            self.mrgb = torch.empty((max(1, world_size), n, 3), dtype=torch.float32, device=dev)
+            self.cams = torch.zeros((max(1, world_size), 3), dtype=torch.float32, device=dev)
+            self.g48 = None
+        else:
+            self.g48 = torch.empty((n, 48), dtype=torch.float32, device=dev)
         self.step_id = 0
 
     # ---- pieces ----
@@ -140,17 +150,46 @@ class NativeTrainStep:
         loss = photometric_loss(pred_rgb, batch.rgb_gt)
         loss.backward()  # image-sized autograd only
         _, sensor, poses, _, _ = self._ctx
-        self.raster.trace_bwd(self.step_id, m.n_active_features, self.act, m.features, batch.rays_ori.contiguous(),
-                              batch.rays_dir.contiguous(), None, sensor, poses.timestamps_us[0], poses.timestamps_us[1],
-                              poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_leaf.grad, dist_, None,
-                              raw_parameter_grads=True, out=(self.g12, self.g48))
-        if self.world_size > 1:
-            allreduce_mean_([self.g48, self.g12], self.world_size)
+        bwd_args = (self.step_id, m.n_active_features, self.act, m.features, batch.rays_ori.contiguous(),
+                    batch.rays_dir.contiguous(), None, sensor, poses.timestamps_us[0], poses.timestamps_us[1],
+                    poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_leaf.grad, dist_, None)
+        vmask = None
+        if self.fused:
+            w = max(1, self.world_size)
+            self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, compact_radiance_grads=True,
+                                  out=(self.g12, self.mrgb[self.rank if w > 1 else 0]))
+            cam_local = batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32).contiguous()
+            if w > 1:
+                work = dist.all_reduce(self.g12, op=dist.ReduceOp.SUM, async_op=True)
+                allgather_rows_(self.mrgb, self.mrgb[self.rank], w)
+                allgather_rows_(self.cams, cam_local, w)
+                work.wait()
+                if self.selective:
+                    allreduce_max_(vis, w)
+            else:
+                self.cams[0].copy_(cam_local)
             if self.selective:
-                allreduce_max_(vis, self.world_size)
-        vmask = vis.reshape(-1) if self.selective else None
-        self._adam(m.raw, self.g12, self.m12, self.v12, self.lr12, vmask)
-        self._adam(m.features, self.g48, self.m48, self.v48, self.lr48, vmask)
+                vmask = vis.reshape(-1)
+            cams_host = self.cams.cpu().numpy().astype(np.float32).reshape(-1)
+            st = torch.cuda.current_stream(m.raw.device).cuda_stream
+            f32p = C.POINTER(C.c_float)
+            rc = self._lib.gut_sh_adam_step(
+                C.c_void_p(st), m.num_gaussians, m.n_active_features, w, cams_host.ctypes.data_as(f32p), self.mrgb.data_ptr(),
+                self.g12.data_ptr(), 1.0 / w, m.raw.data_ptr(), self.m12.data_ptr(), self.v12.data_ptr(), m.features.data_ptr(),
+                self.m48.data_ptr(), self.v48.data_ptr(), self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p),
+                self.betas[0], self.betas[1], self.eps, 0 if self.selective else self.step_id + 1,
+                None if vmask is None else vmask.data_ptr())
+            if rc:
+                raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
+        else:
+            self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, out=(self.g12, self.g48))
+            if self.world_size > 1:
+                allreduce_mean_([self.g48, self.g12], self.world_size)
+                if self.selective:
+                    allreduce_max_(vis, self.world_size)
+            vmask = vis.reshape(-1) if self.selective else None
+            self._adam(m.raw, self.g12, self.m12, self.v12, self.lr12, vmask)
+            self._adam(m.features, self.g48, self.m48, self.v48, self.lr48, vmask)
         self.step_id += 1
         return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
 

@@ -203,7 +203,7 @@ class SplatRaster:
 
     def trace_bwd(self, frame_number, num_active_features, particle_density, particle_radiance, ray_ori, ray_dir, ray_time,
                   sensor_params, ts_start, ts_end, pose_start, pose_end, ray_radiance_density, ray_radiance_density_grd,
-                  ray_hit_distance, ray_hit_distance_grd, raw_parameter_grads=False, out=None):
+                  ray_hit_distance, ray_hit_distance_grd, raw_parameter_grads=False, compact_radiance_grads=False, out=None):
         ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
         ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
         H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
@@ -218,7 +218,7 @@ class SplatRaster:
             dens_g, sph_g = out
         else:
             dens_g = torch.empty((n, 12), **opts)  # fully written by the per-Gaussian epilogue kernel
-            sph_g = torch.empty((n, 48), **opts)
+            sph_g = torch.empty((n, 3 if compact_radiance_grads else 48), **opts)
         if n:
             particle_density = _check_f32_cuda(particle_density, "particleDensity", (12,))
             particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
@@ -232,7 +232,8 @@ class SplatRaster:
                                          ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(), rgba_g.data_ptr(),
                                          dist.data_ptr(), None if dist_g is None else dist_g.data_ptr(), dens_g.data_ptr() if n else None,
                                          sph_g.data_ptr() if n else None,
-                                         _capi.BWD_RAW_PARAMETER_GRADS if raw_parameter_grads else 0)
+                                         (_capi.BWD_RAW_PARAMETER_GRADS if raw_parameter_grads else 0) |
+                                         (_capi.BWD_COMPACT_RADIANCE_GRADS if compact_radiance_grads else 0))
         _capi.check(rc, "trace_bwd")
         return dens_g, sph_g
 

@@ -146,6 +146,10 @@ int gut_trace_bwd(gut_handle h, void* stream, uint32_t frame_number, int32_t num
  * (density logit, un-normalised quaternion, log-scale), i.e. chained through sigmoid / normalise / exp
  * (threedgrut/model/model.py:74-93), ready for gut_adam_step. */
 #define GUT_BWD_RAW_PARAMETER_GRADS 1u
+/* GUT_BWD_COMPACT_RADIANCE_GRADS (implies raw parameter gradients): d_particle_radiance_grad receives only [N,3] =
+ * dL/dRGB masked by (precomputed RGB > 0) instead of the [N,48] SH gradient; the SH gradient of the view is
+ * Y_k(dir) (x) that row and is rebuilt by gut_sh_adam_step (also across several views: compact data-parallel exchange). */
+#define GUT_BWD_COMPACT_RADIANCE_GRADS 2u
 int gut_trace_bwd_ex(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features,
                      uint32_t num_particles, const float* d_particle_density, const float* d_particle_radiance,
                      int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
@@ -198,6 +202,19 @@ int gut_activate_pack(void* stream, uint32_t num_particles, const float* d_raw12
 int gut_adam_step(void* stream, uint64_t rows, uint32_t cols, float* d_param, const float* d_grad, float* d_exp_avg,
                   float* d_exp_avg_sq, const float* lr_per_col, float beta1, float beta2, float eps, uint32_t step,
                   const float* d_visibility);
+
+/* Fused "SH gradient + Adam" step of the native trainer.  For every Gaussian: Adam on the raw [N,12] row with
+ * d_raw_grad12 (already summed over views), then the [N,48] SH row with the gradient
+ *     sum_v Y_k(normalize(pos - camera_position[v])) * mrgb[v][i][c]   (k < (sh_degree+1)^2, else 0)
+ * rebuilt on the fly from num_views compact rows (gut_trace_bwd_ex(..., GUT_BWD_COMPACT_RADIANCE_GRADS)); both
+ * gradients are scaled by grad_scale (1/num_views for a mean over views).  pos is the pre-update position.
+ * lr12/lr48: host arrays of per-column learning rates; step/visibility as in gut_adam_step.  num_views <= 16. */
+int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views,
+                     const float* camera_positions /* host [num_views,3] */, const float* d_mrgb /* [num_views,N,3] */,
+                     const float* d_raw_grad12, float grad_scale,
+                     float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
+                     const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
+                     const float* d_visibility);
 
 const char* gut_last_error(void);
 int gut_abi_version(void);

@@ -58,8 +58,9 @@ def test_selective_adam_semantics():
     assert rel_l2(p[0::2].cpu().numpy(), exp[0::2].cpu().numpy()) <= 1e-6
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("steps", [1, 3])
-def test_native_step_matches_autograd_step(steps):
+def test_native_step_matches_autograd_step(steps, fused):
     sc = scenes.scene_c1(800, 21)
     view = make_view("pinhole", 96, 80, cams.look_at_c2w((0.2, -0.1, -3.5), (0, 0, 0)), fx=90)
     batch = to_batch(view, DEV)
@@ -69,7 +70,7 @@ def test_native_step_matches_autograd_step(steps):
     ta = train.TrainStep(ma, gut.Tracer({"render": {}}), scene_extent=1.0)
     # native path
     mn = native.NativeGaussianModel(sc, device=DEV)
-    tn = native.NativeTrainStep(mn, gut.Tracer({"render": {}}), scene_extent=1.0)
+    tn = native.NativeTrainStep(mn, gut.Tracer({"render": {}}), scene_extent=1.0, fused_sh_adam=fused)
     for _ in range(steps):
         la, _ = ta.step(batch)
         ln, _ = tn.step(batch)
