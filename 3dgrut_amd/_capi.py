@@ -100,7 +100,7 @@ def load():
     lib.gut_adam_step.argtypes = [vp, C.c_uint64, u32, vp, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float,
                                   C.c_float, u32, vp]
     fptr = C.POINTER(C.c_float)
-    lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, fptr, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
+    lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
                                      C.c_float, C.c_float, C.c_float, u32, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_adam_step(AdamParams ap, uint64_t n_
 // ---------------------------------------------------------------------------------------------------
 struct ShAdamParams {
     AdamParams a12, a48;
-    float cam[16][3];
+    const float* cam;  // device [views,3]: sensor positions in world space
     uint32_t n, views;
     int32_t sh_degree;
     float grad_scale;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
                 const float* mr = mrgb + ((size_t)vw * sp.n + i) * 3;
                 const float r = mr[0] * sp.grad_scale, g = mr[1] * sp.grad_scale, bl = mr[2] * sp.grad_scale;
                 if (r == 0.0f && g == 0.0f && bl == 0.0f) continue;
-                const float dx = px - sp.cam[vw][0], dy = py - sp.cam[vw][1], dz = pz - sp.cam[vw][2];
+                const float dx = px - sp.cam[3 * vw + 0], dy = py - sp.cam[3 * vw + 1], dz = pz - sp.cam[3 * vw + 2];
                 const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
                 float Y[16];
                 sh_basis_fast(sp.sh_degree, dx * inv, dy * inv, dz * inv, Y);
@@ -235,20 +235,19 @@ static void fill_adam(gut::AdamParams& ap, const float* lr, uint32_t cols, float
     }
 }
 
-int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* camera_positions,
+int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* d_camera_positions,
                      const float* d_mrgb, const float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
                      float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
                      float beta1, float beta2, float eps, uint32_t step, const float* d_visibility) {
     if (num_particles == 0) return 0;
-    if (!camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
+    if (!d_camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
         !lr12 || !lr48)
         return 1;
-    if (num_views == 0 || num_views > 16 || sh_degree < 0 || sh_degree > 3) return 3;
+    if (num_views == 0 || num_views > 1024 || sh_degree < 0 || sh_degree > 3) return 3;
     gut::ShAdamParams sp;
     fill_adam(sp.a12, lr12, 12, beta1, beta2, eps, step);
     fill_adam(sp.a48, lr48, 48, beta1, beta2, eps, step);
-    for (uint32_t v = 0; v < 16; ++v)
-        for (int k = 0; k < 3; ++k) sp.cam[v][k] = v < num_views ? camera_positions[3 * v + k] : 0.0f;
+    sp.cam = d_camera_positions;
     sp.n = num_particles; sp.views = num_views; sp.sh_degree = sh_degree; sp.grad_scale = grad_scale;
     hipLaunchKernelGGL(gut::k_sh_adam, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
                        static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<const float4*>(d_raw_grad12),

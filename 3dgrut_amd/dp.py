@@ -9,6 +9,12 @@ import torch
 import torch.distributed as dist
 
 
+def _stage_on_cpu(t, group=None) -> bool:
+    """gloo cannot reduce device tensors on every build: stage through host memory there (tests only; the GPU box
+    runs RCCL, which takes device tensors directly)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def view_index(step: int, rank: int, world: int, n_views: int) -> int:
     """Rank r's view in step s: a contiguous block of `world` views per step, wrapped over the dataset."""
     return (step * world + rank) % n_views
@@ -18,18 +24,44 @@ def allreduce_mean_(tensors, world: int, group=None):
     """In-place mean over ranks of every tensor in `tensors` (largest first so the big SH message starts early)."""
     if world <= 1:
         return
+    inv = 1.0 / world
+    if any(_stage_on_cpu(t, group) for t in tensors):
+        for t in tensors:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h.mul_(inv))
+        return
     works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
              for t in sorted(tensors, key=lambda t: -t.numel())]
     for w in works:
         w.wait()
-    inv = 1.0 / world
     for t in tensors:
         t.mul_(inv)
 
 
 def allreduce_max_(tensor, world: int, group=None):
     if world > 1:
-        dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group)
+        if _stage_on_cpu(tensor, group):
+            h = tensor.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            tensor.copy_(h)
+        else:
+            dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group)
+
+
+def allreduce_sum_async(tensor, world: int, group=None):
+    """SUM all-reduce; returns an object with .wait() (no-op object for world 1 / host-staged backends)."""
+    class _Done:
+        def wait(self):
+            return None
+    if world <= 1:
+        return _Done()
+    if _stage_on_cpu(tensor, group):
+        h = tensor.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        tensor.copy_(h)
+        return _Done()
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 
 def allgather_rows_(out, local, world: int, group=None):
@@ -37,6 +69,12 @@ def allgather_rows_(out, local, world: int, group=None):
     if world <= 1:
         if out[0].data_ptr() != local.data_ptr():
             out[0].copy_(local)
+        return
+    if _stage_on_cpu(local, group):
+        parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
+        dist.all_gather(parts, local.cpu(), group=group)
+        for r, t in enumerate(parts):
+            out[r].copy_(t)
         return
     try:
         dist.all_gather_into_tensor(out, local, group=group)

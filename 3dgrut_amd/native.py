@@ -17,10 +17,9 @@ import math
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from . import _capi
-from .dp import allgather_rows_, allreduce_max_, allreduce_mean_
+from .dp import allgather_rows_, allreduce_max_, allreduce_mean_, allreduce_sum_async
 from .losses import photometric_loss
 from .tracer import SplatRaster, Tracer
 
@@ -160,7 +159,7 @@ class NativeTrainStep:
                                   out=(self.g12, self.mrgb[self.rank if w > 1 else 0]))
             cam_local = batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32).contiguous()
             if w > 1:
-                work = dist.all_reduce(self.g12, op=dist.ReduceOp.SUM, async_op=True)
+                work = allreduce_sum_async(self.g12, w)
                 allgather_rows_(self.mrgb, self.mrgb[self.rank], w)
                 allgather_rows_(self.cams, cam_local, w)
                 work.wait()
@@ -170,11 +169,10 @@ class NativeTrainStep:
                 self.cams[0].copy_(cam_local)
             if self.selective:
                 vmask = vis.reshape(-1)
-            cams_host = self.cams.cpu().numpy().astype(np.float32).reshape(-1)
             st = torch.cuda.current_stream(m.raw.device).cuda_stream
             f32p = C.POINTER(C.c_float)
             rc = self._lib.gut_sh_adam_step(
-                C.c_void_p(st), m.num_gaussians, m.n_active_features, w, cams_host.ctypes.data_as(f32p), self.mrgb.data_ptr(),
+                C.c_void_p(st), m.num_gaussians, m.n_active_features, w, self.cams.data_ptr(), self.mrgb.data_ptr(),
                 self.g12.data_ptr(), 1.0 / w, m.raw.data_ptr(), self.m12.data_ptr(), self.v12.data_ptr(), m.features.data_ptr(),
                 self.m48.data_ptr(), self.v48.data_ptr(), self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p),
                 self.betas[0], self.betas[1], self.eps, 0 if self.selective else self.step_id + 1,
