@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--render-frames", type=int, default=10)
     ap.add_argument("--trainer", default="native", choices=["native", "autograd"],
                     help="native: fused HIP activation/Adam around the renderer; autograd: torch.autograd + torch.optim.Adam")
+    ap.add_argument("--dense-exchange", action="store_true",
+                    help="native trainer: materialise the [N,48] SH gradient and all-reduce it (default: compact exchange + fused SH-grad/Adam)")
     ap.add_argument("--selective-adam", action="store_true", help="visibility-masked Adam (reference SelectiveAdam)")
     args = ap.parse_args()
 
@@ -154,7 +156,8 @@ def main():
     if args.trainer == "native":
         native_mod = importlib.import_module("3dgrut_amd.native")
         model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree)
-        stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam)
+        stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
+                                             rank=rank, fused_sh_adam=not args.dense_exchange)
     else:
         model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
         stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
@@ -222,9 +225,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "num_gaussians": int(stats["num_particles"]), "resolution": [W, H],
-                       "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}",
+                       "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}" + ("" if world == 1 else (" dense all-reduce [N,60]" if (args.dense_exchange or args.trainer != "native") else " all-reduce [N,12] + all-gather [N,3]")),
                        "loss": "0.8*L1+0.2*(1-SSIM) (HIP fused SSIM)",
-                       "optimizer": ("HIP fused Adam" if args.trainer == "native" else "torch.optim.Adam(fused)") +
+                       "optimizer": (("HIP fused SH-gradient+Adam" if not args.dense_exchange else "HIP fused Adam") if args.trainer == "native" else "torch.optim.Adam(fused)") +
                                     (" selective(visibility)" if args.selective_adam else "") + ", all 59 params/Gaussian",
                        "trainer": args.trainer},
             "render_ms_per_frame": render_ms,
