@@ -154,9 +154,19 @@ namespace {
 int build_view(const GutCamera* cam, int W, int H, gut::ViewParams* v) {
     if (cam->model != GUT_CAMERA_OPENCV_PINHOLE && cam->model != GUT_CAMERA_OPENCV_FISHEYE)
         return fail("unsupported camera model %d (only OpenCV pinhole / fisheye exist in the reference)", cam->model);
-    if (cam->shutter != GUT_SHUTTER_GLOBAL)
-        return fail("rolling-shutter type %d is not implemented in this build (global shutter only)", cam->shutter);
+    if (cam->shutter < GUT_SHUTTER_ROLLING_TOP_TO_BOTTOM || cam->shutter > GUT_SHUTTER_GLOBAL)
+        return fail("unknown shutter type %d", cam->shutter);
     memset(v, 0, sizeof(*v));
+    v->shutter = cam->shutter;
+    for (int i = 0; i < 7; ++i) {
+        v->pose_start[i] = cam->pose_start[i];
+        v->pose_end[i] = cam->pose_end[i];
+    }
+    {
+        const float* e = cam->pose_end;
+        quat_to_rot(e[6], e[3], e[4], e[5], v->w2s_end.r);
+        for (int i = 0; i < 3; ++i) v->w2s_end.t[i] = e[i];
+    }
     const float* s = cam->pose_start;
     quat_to_rot(s[6], s[3], s[4], s[5], v->w2s_start.r);
     for (int i = 0; i < 3; ++i) v->w2s_start.t[i] = s[i];
@@ -281,6 +291,7 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
     if (cfg->particle_radiance_sph_degree != 3) return fail("particle_radiance_sph_degree=%d: only degree 3 (16 coefficients) is built", cfg->particle_radiance_sph_degree);
     if (cfg->ut_require_all_sigma_points != 0) return fail("ut_require_all_sigma_points must be false (static_assert in threedgut.cuh:73)");
     if (!cfg->enable_hitcounts) return fail("enable_hitcounts=false is not built");
+    if (cfg->n_rolling_shutter_iterations != 5) return fail("n_rolling_shutter_iterations=%d: only 5 (render/3dgut.yaml) is built", cfg->n_rolling_shutter_iterations);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_index < 0 || device_index >= ndev) return fail("gut_create: device %d out of range (%d devices)", device_index, ndev);

@@ -19,6 +19,9 @@ struct Affine {
 
 // Everything the device code needs to know about the view; built on the host (gut_api.cpp).
 struct ViewParams {
+    Affine w2s_end;     // world->sensor at the end pose (rolling-shutter fallback, cameraProjections.cuh:162-170)
+    float pose_start[7], pose_end[7];  // t(3), q(x,y,z,w): interpolated per sigma point for rolling shutters
+    int32_t shutter;
     Affine w2s_start;   // world->sensor at the start pose: projects the sigma points (cameraProjections.cuh:154-157)
     Affine w2s_mid;     // world->sensor at the interpolated mid pose: depth key (gutProjector.cuh:137,317)
     Affine s2w;         // sensor->world: ray transform; s2w.t is the sensor position in world space

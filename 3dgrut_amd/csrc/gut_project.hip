@@ -129,18 +129,110 @@ __device__ __forceinline__ bool project_fisheye(const ViewParams& v, float px, f
     return (theta < v.max_angle) && within_resolution((float)v.width, (float)v.height, tol, ox, oy);
 }
 
+// acos on [0,1] / sin on [0, pi/2] for the rolling-shutter slerp: fdlibm e_acosf / k_sinf / k_cosf in plain fp32
+__device__ float det_acosf01(float x) {
+    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    if (x >= 1.0f) return 0.0f;
+    if (x < 0.5f) {
+        const float z = x * x;
+        const float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    const float z = (1.0f - x) * 0.5f;
+    const float sq = sqrtf(z);
+    const float df = u2f(f2u(sq) & 0xfffff000u);
+    const float c = (z - df * df) / (sq + df);
+    const float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+    const float w = r * sq + c;
+    return 2.0f * (df + w);
+}
+__device__ float det_sinf_0_pio2(float x) {
+    if (x <= 0.78539818525f) {
+        const float z = x * x;
+        const float vv = z * x;
+        const float r = 8.3333337680e-03f + z * (-1.9841270114e-04f + z * (2.7557314297e-06f + z * (-2.5050759689e-08f + z * 1.5896910177e-10f)));
+        return x + vv * (-1.6666667163e-01f + z * r);
+    }
+    const float y = (1.5707962513e+00f - x) + 7.5497894159e-08f;
+    const float z = y * y;
+    const float r = z * (4.1666667908e-02f + z * (-1.3888889225e-03f + z * (2.4801587642e-05f + z * (-2.7557314297e-07f + z * (2.0875723372e-09f + z * -1.1359647598e-11f)))));
+    return 1.0f - (0.5f * z - z * r);
+}
+
 // kVariant: 0 = pinhole without distortion, 1 = pinhole with distortion, 2 = fisheye (compile-time specialisation of
 // the reference's run-time camera-model switch, cameraProjections.cuh:130-144)
 template <int kVariant>
-__device__ __forceinline__ int project_world(const ViewParams& v, float wx, float wy, float wz, float tol, float& ox,
-                                             float& oy) {
-    const Affine& a = v.w2s_start;
-    const float cx = a.r[0][0] * wx + a.r[0][1] * wy + a.r[0][2] * wz + a.t[0];
-    const float cy = a.r[1][0] * wx + a.r[1][1] * wy + a.r[1][2] * wz + a.t[1];
-    const float cz = a.r[2][0] * wx + a.r[2][1] * wy + a.r[2][2] * wz + a.t[2];
+__device__ __forceinline__ int project_camera(const ViewParams& v, float cx, float cy, float cz, float tol, float& ox, float& oy) {
     if (kVariant == 0) return project_pinhole<false>(v, cx, cy, cz, tol, ox, oy) ? 1 : 0;
     if (kVariant == 1) return project_pinhole<true>(v, cx, cy, cz, tol, ox, oy) ? 1 : 0;
     return project_fisheye(v, cx, cy, cz, tol, ox, oy) ? 1 : 0;
+}
+
+__device__ __forceinline__ float relative_shutter_time(const ViewParams& v, float px, float py) {
+    switch (v.shutter) {
+    case GUT_SHUTTER_ROLLING_TOP_TO_BOTTOM: return floorf(py) / ((float)v.height - 1.0f);
+    case GUT_SHUTTER_ROLLING_LEFT_TO_RIGHT: return floorf(px) / ((float)v.width - 1.0f);
+    case GUT_SHUTTER_ROLLING_BOTTOM_TO_TOP: return ((float)v.height - ceilf(py)) / ((float)v.height - 1.0f);
+    case GUT_SHUTTER_ROLLING_RIGHT_TO_LEFT: return ((float)v.width - ceilf(px)) / ((float)v.width - 1.0f);
+    default: return 0.5f;
+    }
+}
+
+// world point -> sensor space at relative shutter time a: slerp of the two pose quaternions + mix of the translations
+__device__ void shutter_pose_transform(const ViewParams& v, float a, float wx, float wy, float wz, float& cx, float& cy,
+                                       float& cz) {
+    const float* ps = v.pose_start;
+    const float* pe = v.pose_end;
+    float q0[4] = {ps[6], ps[3], ps[4], ps[5]}, q1[4] = {pe[6], pe[3], pe[4], pe[5]}, q[4];
+    float cosT = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
+    if (cosT < 0.0f) {
+        for (int i = 0; i < 4; ++i) q1[i] = -q1[i];
+        cosT = -cosT;
+    }
+    if (cosT > 1.0f - 1.1920929e-07f) {
+        for (int i = 0; i < 4; ++i) q[i] = q0[i] * (1.0f - a) + q1[i] * a;
+    } else {
+        const float ang = det_acosf01(cosT);
+        const float s0 = det_sinf_0_pio2((1.0f - a) * ang), s1 = det_sinf_0_pio2(a * ang), sd = det_sinf_0_pio2(ang);
+        for (int i = 0; i < 4; ++i) q[i] = (s0 * q0[i] + s1 * q1[i]) / sd;
+    }
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float qxx = x * x, qyy = y * y, qzz = z * z, qxz = x * z, qxy = x * y, qyz = y * z, qwx = w * x, qwy = w * y, qwz = w * z;
+    // GLM mat3_cast, columns c0,c1,c2
+    const float r00 = 1.0f - 2.0f * (qyy + qzz), r10 = 2.0f * (qxy + qwz), r20 = 2.0f * (qxz - qwy);
+    const float r01 = 2.0f * (qxy - qwz), r11 = 1.0f - 2.0f * (qxx + qzz), r21 = 2.0f * (qyz + qwx);
+    const float r02 = 2.0f * (qxz + qwy), r12 = 2.0f * (qyz - qwx), r22 = 1.0f - 2.0f * (qxx + qyy);
+    const float t0 = ps[0] * (1.0f - a) + pe[0] * a, t1 = ps[1] * (1.0f - a) + pe[1] * a, t2 = ps[2] * (1.0f - a) + pe[2] * a;
+    cx = r00 * wx + r01 * wy + r02 * wz + t0;
+    cy = r10 * wx + r11 * wy + r12 * wz + t1;
+    cz = r20 * wx + r21 * wy + r22 * wz + t2;
+}
+
+// projectPointWithShutter<5> (cameraProjections.cuh:146-185)
+template <int kVariant, bool kRolling>
+__device__ __forceinline__ int project_world(const ViewParams& v, float wx, float wy, float wz, float tol, float& ox,
+                                             float& oy) {
+    const Affine& a = v.w2s_start;
+    float cx = a.r[0][0] * wx + a.r[0][1] * wy + a.r[0][2] * wz + a.t[0];
+    float cy = a.r[1][0] * wx + a.r[1][1] * wy + a.r[1][2] * wz + a.t[1];
+    float cz = a.r[2][0] * wx + a.r[2][1] * wy + a.r[2][2] * wz + a.t[2];
+    int valid = project_camera<kVariant>(v, cx, cy, cz, tol, ox, oy);
+    if (!kRolling) return valid;
+    if (!valid) {
+        const Affine& e = v.w2s_end;
+        cx = e.r[0][0] * wx + e.r[0][1] * wy + e.r[0][2] * wz + e.t[0];
+        cy = e.r[1][0] * wx + e.r[1][1] * wy + e.r[1][2] * wz + e.t[1];
+        cz = e.r[2][0] * wx + e.r[2][1] * wy + e.r[2][2] * wz + e.t[2];
+        valid = project_camera<kVariant>(v, cx, cy, cz, tol, ox, oy);
+        if (!valid) return 0;
+    }
+    for (int it = 0; it < 5; ++it) {
+        const float al = relative_shutter_time(v, ox, oy);
+        shutter_pose_transform(v, al, wx, wy, wz, cx, cy, cz);
+        valid = project_camera<kVariant>(v, cx, cy, cz, tol, ox, oy);
+    }
+    return valid;
 }
 
 // rows of rotationT from a wxyz quaternion (slang/common/transforms.slang:22-39)
@@ -248,7 +340,7 @@ constexpr int kShRow = 49;  // padded LDS row stride (dwords)
 __device__ __forceinline__ float bcast(float v, int src_lane) { return __shfl(v, src_lane); }
 __device__ __forceinline__ int bcast(int v, int src_lane) { return __shfl(v, src_lane); }
 
-template <int kVariant>
+template <int kVariant, bool kRolling>
 __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, RenderConsts c, uint32_t n, int sh_degree,
                                                             const float4* __restrict__ density12,
                                                             const float* __restrict__ sph48,
@@ -281,17 +373,17 @@ __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, Rende
             quat_rows(b.x, b.y, b.z, b.w, rows);
             const float scl[3] = {d.x, d.y, d.z};
             float sx[7], sy[7];
-            int nvalid = project_world<kVariant>(v, a.x, a.y, a.z, c.ut_margin, sx[0], sy[0]);
+            int nvalid = project_world<kVariant, kRolling>(v, a.x, a.y, a.z, c.ut_margin, sx[0], sy[0]);
             cx = sx[0] * c.ut_w0_mean;
             cy = sy[0] * c.ut_w0_mean;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float kk = c.ut_delta * scl[k];
                 const float dx = kk * rows[k][0], dy = kk * rows[k][1], dz = kk * rows[k][2];
-                nvalid += project_world<kVariant>(v, a.x + dx, a.y + dy, a.z + dz, c.ut_margin, sx[k + 1], sy[k + 1]);
+                nvalid += project_world<kVariant, kRolling>(v, a.x + dx, a.y + dy, a.z + dz, c.ut_margin, sx[k + 1], sy[k + 1]);
                 cx += c.ut_wi * sx[k + 1];
                 cy += c.ut_wi * sy[k + 1];
-                nvalid += project_world<kVariant>(v, a.x - dx, a.y - dy, a.z - dz, c.ut_margin, sx[k + 4], sy[k + 4]);
+                nvalid += project_world<kVariant, kRolling>(v, a.x - dx, a.y - dy, a.z - dz, c.ut_margin, sx[k + 4], sy[k + 4]);
                 cx += c.ut_wi * sx[k + 4];
                 cy += c.ut_wi * sy[k + 4];
             }
@@ -728,7 +820,9 @@ void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, u
     for (float k : v.tangential) distorted |= (k != 0.0f);
     for (float k : v.thin_prism) distorted |= (k != 0.0f);
     const int variant = v.model == GUT_CAMERA_OPENCV_FISHEYE ? 2 : (distorted ? 1 : 0);
-    auto kern = variant == 0 ? k_project_on_tiles<0> : (variant == 1 ? k_project_on_tiles<1> : k_project_on_tiles<2>);
+    const bool rolling = v.shutter != GUT_SHUTTER_GLOBAL;
+    auto kern = rolling ? (variant == 0 ? k_project_on_tiles<0, true> : (variant == 1 ? k_project_on_tiles<1, true> : k_project_on_tiles<2, true>))
+                        : (variant == 0 ? k_project_on_tiles<0, false> : (variant == 1 ? k_project_on_tiles<1, false> : k_project_on_tiles<2, false>));
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), sph48, tiles_count, reinterpret_cast<float2*>(proj_pos),
                        reinterpret_cast<float4*>(conic_opacity), reinterpret_cast<float2*>(extent), depth, feat, visibility,

@@ -40,7 +40,7 @@ enum { GUT_CAMERA_OPENCV_PINHOLE = 0, GUT_CAMERA_OPENCV_FISHEYE = 1 };
  * (bindings.cpp:34-77) and toSensorState (splatRaster.cpp:92-100). */
 typedef struct GutCamera {
     int32_t model;              /* GUT_CAMERA_* */
-    int32_t shutter;            /* GUT_SHUTTER_* (only GLOBAL is implemented in this round) */
+    int32_t shutter;            /* GUT_SHUTTER_* */
     float principal_point[2];
     float focal_length[2];
     float radial_coeffs[6];     /* pinhole: k1..k6 ; fisheye: k1..k4 in [0..3] */
@@ -64,7 +64,7 @@ typedef struct GutConfig {
     int32_t particle_kernel_degree;       /* 2 (quadratic) */
     int32_t k_buffer_size;                /* 0 (unsorted) */
     int32_t global_z_order;               /* 1 */
-    int32_t n_rolling_shutter_iterations; /* 5 (unused: global shutter only) */
+    int32_t n_rolling_shutter_iterations; /* 5 (the only value built) */
     int32_t ut_require_all_sigma_points;  /* 0 */
     int32_t rect_bounding, tight_opacity_bounding, tile_based_culling; /* 1,1,1 */
     int32_t enable_hitcounts;             /* 1 */

@@ -51,7 +51,7 @@ typedef struct {
 
 typedef struct {
     int32_t model;   /* 0 = OpenCV pinhole, 1 = OpenCV fisheye        (sensors/cameraModels.h:42-47) */
-    int32_t shutter; /* 4 = global; 0..3 rolling (unsupported here)   (sensors/cameraModels.h:34-40) */
+    int32_t shutter; /* 4 = global; 0..3 rolling                      (sensors/cameraModels.h:34-40) */
     float principal_point[2];
     float focal_length[2];
     float radial[6];      /* pinhole k1..k6; fisheye k1..k4 in radial[0..3] */
@@ -122,6 +122,47 @@ static float det_atan2f_pos(float y, float x) {
     return a;
 }
 
+/* acos(x) for x in [0,1] and sin(x) for x in [0, pi/2]: fdlibm e_acosf.c / k_sinf.c / k_cosf.c algorithms in plain
+ * fp32 (+,-,*,/,sqrt, bit masks).  Used only by the rolling-shutter slerp inside the projection, where the device
+ * and the host must agree bit for bit. */
+static float det_acosf01(float x) {
+    const float pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const float pS0 = 1.6666586697e-01f, pS1 = -4.2743422091e-02f, pS2 = -8.6563630030e-03f, qS1 = -7.0662963390e-01f;
+    if (x >= 1.0f) return 0.0f;
+    if (x < 0.5f) {
+        const float z = x * x;
+        const float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    const float z = (1.0f - x) * 0.5f;
+    const float sq = sqrtf(z);
+    const float df = u2f(f2u(sq) & 0xfffff000u);
+    const float c = (z - df * df) / (sq + df);
+    const float r = (z * (pS0 + z * (pS1 + z * pS2))) / (1.0f + z * qS1);
+    const float w = r * sq + c;
+    return 2.0f * (df + w);
+}
+static float det_ksinf(float x) { /* |x| <= pi/4 */
+    const float S1 = -1.6666667163e-01f, S2 = 8.3333337680e-03f, S3 = -1.9841270114e-04f, S4 = 2.7557314297e-06f,
+                S5 = -2.5050759689e-08f, S6 = 1.5896910177e-10f;
+    const float z = x * x;
+    const float v = z * x;
+    const float r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x + v * (S1 + z * r);
+}
+static float det_kcosf(float x) { /* |x| <= pi/4 */
+    const float C1 = 4.1666667908e-02f, C2 = -1.3888889225e-03f, C3 = 2.4801587642e-05f, C4 = -2.7557314297e-07f,
+                C5 = 2.0875723372e-09f, C6 = -1.1359647598e-11f;
+    const float z = x * x;
+    const float r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    return 1.0f - (0.5f * z - z * r);
+}
+static float det_sinf_0_pio2(float x) { /* x in [0, pi/2] */
+    if (x <= 0.78539818525f) return det_ksinf(x);
+    const float y = (1.5707962513e+00f - x) + 7.5497894159e-08f;
+    return det_kcosf(y);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * host-side pose math (float)
  * tiny-cuda-nn is not vendored: to_mat3 / quat(mat3) / slerp / mix are restated with
@@ -160,6 +201,7 @@ static void interpolate_pose(const float* a, const float* b, float t, float* out
 }
 
 typedef struct {
+    M3 Re; float te[3];      /* end pose world->sensor (rolling shutter fallback, cameraProjections.cuh:162-170) */
     M3 Rs; float ts[3];      /* start pose world->sensor (projection of sigma points, cameraProjections.cuh:154-157) */
     M3 Rm; float tm[3];      /* mid pose world->sensor (depth key, gutProjector.cuh:137,317) */
     M3 Rinv; float cam[3];   /* sensor->world (ray transform rayPayload.cuh:93-94) and sensor world position */
@@ -170,6 +212,9 @@ static PoseSet make_pose_set(const OracleCamera* cam) {
     const float* s = cam->pose_start;
     p.Rs = quat_to_mat3(s[6], s[3], s[4], s[5]);
     p.ts[0] = s[0]; p.ts[1] = s[1]; p.ts[2] = s[2];
+    const float* e = cam->pose_end;
+    p.Re = quat_to_mat3(e[6], e[3], e[4], e[5]);
+    p.te[0] = e[0]; p.te[1] = e[1]; p.te[2] = e[2];
     float mid[7];
     interpolate_pose(cam->pose_start, cam->pose_end, 0.5f, mid);
     p.Rm = quat_to_mat3(mid[6], mid[3], mid[4], mid[5]);
@@ -269,15 +314,62 @@ static int project_fisheye(const OracleCamera* c, int W, int H, const float p[3]
     return (theta < c->max_angle) && within_resolution((float)W, (float)H, tol, out[0], out[1]);
 }
 
-/* projectPointWithShutter, global-shutter branch (cameraProjections.cuh:146-160) */
-static int project_world_point(const OracleCamera* c, const PoseSet* ps, int W, int H, const float w[3], float tol, float out[2]) {
-    float p[3];
-    for (int r = 0; r < 3; ++r)
-        p[r] = ps->Rs.c[0][r] * w[0] + ps->Rs.c[1][r] * w[1] + ps->Rs.c[2][r] * w[2] + ps->ts[r];
+static int project_camera_point(const OracleCamera* c, int W, int H, const float p[3], float tol, float out[2]) {
     if (c->model == 0) return project_pinhole(c, W, H, p, tol, out);
     if (c->model == 1) return project_fisheye(c, W, H, p, tol, out);
     out[0] = 0.0f; out[1] = 0.0f;
     return 0;
+}
+
+/* relativeShutterTime, cameraProjections.cuh:35-50 */
+static float relative_shutter_time(int shutter, int W, int H, const float pos[2]) {
+    switch (shutter) {
+    case 0: return floorf(pos[1]) / ((float)H - 1.0f);
+    case 1: return floorf(pos[0]) / ((float)W - 1.0f);
+    case 2: return ((float)H - ceilf(pos[1])) / ((float)H - 1.0f);
+    case 3: return ((float)W - ceilf(pos[0])) / ((float)W - 1.0f);
+    default: return 0.5f;
+    }
+}
+
+/* slerp(q0,q1,a) (GLM definition, w,x,y,z) + mix(t0,t1,a) applied to a world point, deterministic trig */
+static void shutter_pose_transform(const float* ps, const float* pe, float a, const float w[3], float out[3]) {
+    float q0[4] = {ps[6], ps[3], ps[4], ps[5]}, q1[4] = {pe[6], pe[3], pe[4], pe[5]}, q[4];
+    float cosT = q0[0] * q1[0] + q0[1] * q1[1] + q0[2] * q1[2] + q0[3] * q1[3];
+    if (cosT < 0.0f) { for (int i = 0; i < 4; ++i) q1[i] = -q1[i]; cosT = -cosT; }
+    if (cosT > 1.0f - 1.1920929e-07f) {
+        for (int i = 0; i < 4; ++i) q[i] = q0[i] * (1.0f - a) + q1[i] * a;
+    } else {
+        const float ang = det_acosf01(cosT);
+        const float s0 = det_sinf_0_pio2((1.0f - a) * ang), s1 = det_sinf_0_pio2(a * ang), sd = det_sinf_0_pio2(ang);
+        for (int i = 0; i < 4; ++i) q[i] = (s0 * q0[i] + s1 * q1[i]) / sd;
+    }
+    const M3 R = quat_to_mat3(q[0], q[1], q[2], q[3]);
+    for (int r = 0; r < 3; ++r) {
+        const float t = ps[r] * (1.0f - a) + pe[r] * a;
+        out[r] = R.c[0][r] * w[0] + R.c[1][r] * w[1] + R.c[2][r] * w[2] + t;
+    }
+}
+
+/* projectPointWithShutter<5>, cameraProjections.cuh:146-185 */
+static int project_world_point(const OracleCamera* c, const PoseSet* ps, int W, int H, const float w[3], float tol, float out[2]) {
+    float p[3];
+    for (int r = 0; r < 3; ++r)
+        p[r] = ps->Rs.c[0][r] * w[0] + ps->Rs.c[1][r] * w[1] + ps->Rs.c[2][r] * w[2] + ps->ts[r];
+    int valid = project_camera_point(c, W, H, p, tol, out);
+    if (c->shutter == 4) return valid;
+    if (!valid) {
+        for (int r = 0; r < 3; ++r)
+            p[r] = ps->Re.c[0][r] * w[0] + ps->Re.c[1][r] * w[1] + ps->Re.c[2][r] * w[2] + ps->te[r];
+        valid = project_camera_point(c, W, H, p, tol, out);
+        if (!valid) return 0;
+    }
+    for (int it = 0; it < 5; ++it) {
+        const float a = relative_shutter_time(c->shutter, W, H, out);
+        shutter_pose_transform(c->pose_start, c->pose_end, a, w, p);
+        valid = project_camera_point(c, W, H, p, tol, out);
+    }
+    return valid;
 }
 
 /* quaternion (w,x,y,z) -> rows of rotationT — slang/common/transforms.slang:22-39 */

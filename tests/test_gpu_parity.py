@@ -218,9 +218,42 @@ def test_error_behaviour():
         raster.trace(0, 3, d12.double(), sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
     with pytest.raises(RuntimeError):  # unsupported variant is rejected, not silently rendered
         gut.SplatRaster({"render": {"splat": {"k_buffer_size": 16}}})
-    sensor.cam.shutter = 0
+    sensor.cam.shutter = 7  # not a ShutterType
     with pytest.raises(RuntimeError):
         raster.trace(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
+
+
+@pytest.mark.parametrize("shutter", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", ["pinhole", "fisheye"])
+def test_rolling_shutter_projection(shutter, kind):
+    """projectPointWithShutter<5> with distinct start/end poses (cameraProjections.cuh:146-185): tile/key buffers and
+    projection floats stay bit-exact (slerp uses the shared deterministic acos/sin), image within tolerance."""
+    pose_mod = importlib.import_module("3dgrut_amd.pose")
+    sc = scenes.scene_c1(700, 40 + shutter)
+    W, H = 96, 80
+    view = make_view(kind, W, H, cams.look_at_c2w((0.1, 0.0, -3.0 if kind == "pinhole" else -1.6), (0, 0, 0)), fx=90 if kind == "pinhole" else None)
+    end_c2w = cams.look_at_c2w((0.25, -0.1, -2.9 if kind == "pinhole" else -1.55), (0.05, 0.0, 0.0))
+    tq_end = pose_mod.sensor_pose_from_c2w(end_c2w).T_world_sensors[0]
+    ocam = dict(view["oracle_cam"], shutter=shutter, pose_end=tq_end)
+    model, d12, sph = _oracle_inputs(sc, 3)
+    ref = oracle.forward(ocam, W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    raster = gut.SplatRaster({"render": {}})
+    sensor, poses = gut.Tracer.create_camera_parameters(to_batch(view, DEV))
+    sensor.cam.shutter = shutter
+    ro = torch.as_tensor(view["ro"], device=DEV); rd = torch.as_tensor(view["rd"], device=DEV)
+    rgba, dist, hits, vis = raster.trace(0, 3, torch.as_tensor(d12, device=DEV), torch.as_tensor(sph, device=DEV), ro, rd, None, sensor,
+                                         0, 1, poses.T_world_sensors[0], tq_end)
+    assert raster.stats()["num_intersections"] == ref["M"] and ref["M"] > 0
+    for key in ("tiles_count", "sorted_ids"):
+        assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
+    assert np.array_equal(raster.debug_buffer("sorted_keys").cpu().numpy().view(np.uint64), ref["sorted_keys"])
+    for key in ("proj_pos", "conic_opacity", "extent", "depth"):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)), key
+    assert np.abs(rgba.cpu().numpy() - ref["rgba"]).max() <= 2e-4
+    # and the rolling-shutter result must actually differ from the global-shutter one
+    glob = oracle.forward(dict(view["oracle_cam"]), W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    assert not np.array_equal(glob["proj_pos"], ref["proj_pos"])
 
 
 def test_timings_surface():
