@@ -57,7 +57,7 @@ class GutStats(C.Structure):
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
-           "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step")
+           "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
 
 _lib = None
 
@@ -100,6 +100,7 @@ def load():
     lib.gut_adam_step.argtypes = [vp, C.c_uint64, u32, vp, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float,
                                   C.c_float, u32, vp]
     fptr = C.POINTER(C.c_float)
+    lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
                                      C.c_float, C.c_float, C.c_float, u32, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:

@@ -59,6 +59,31 @@ __global__ __launch_bounds__(kBlock) void k_adam_step(AdamParams ap, uint64_t n_
     v[idx] = vv;
 }
 
+// k_mcmc_relocation: new opacity / scale of Gaussians sampled `ratio` times by the MCMC relocation
+// (reference: threedgrut/strategy/src/gaussian_mcmc.cu:33-73; binoms is the [n_max,n_max] Pascal table)
+__global__ __launch_bounds__(kBlock) void k_mcmc_relocation(int n, const float* __restrict__ opacities,
+                                                           const float* __restrict__ scales, const int* __restrict__ ratios,
+                                                           const float* __restrict__ binoms, int n_max,
+                                                           float* __restrict__ new_opacities, float* __restrict__ new_scales) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= n) return;
+    const int n_idx = ratios[idx];
+    const float op = opacities[idx];
+    const float new_op = 1.0f - powf(1.0f - op, 1.0f / (float)n_idx);
+    new_opacities[idx] = new_op;
+    float denom = 0.0f;
+    for (int i = 1; i <= n_idx; ++i) {
+        float pw = new_op;  // new_op^(k+1)
+        for (int k = 0; k <= i - 1; ++k) {
+            const float sign = (k & 1) ? -1.0f : 1.0f;
+            denom += binoms[(i - 1) * n_max + k] * (sign / sqrtf((float)(k + 1))) * pw;
+            pw *= new_op;
+        }
+    }
+    const float coeff = op / denom;
+    for (int c = 0; c < 3; ++c) new_scales[idx * 3 + c] = coeff * scales[idx * 3 + c];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_sh_adam: fused (multi-view) SH-gradient rebuild + Adam for both parameter tensors, one wave per 64 Gaussians.
 // The [N,48] SH gradient never exists in memory: each lane rebuilds its Gaussian's 48 gradient values from the
@@ -221,6 +246,16 @@ int gut_adam_step(void* stream, uint64_t rows, uint32_t cols, float* d_param, co
     hipLaunchKernelGGL(gut::k_adam_step, dim3((uint32_t)blocks), dim3(gut::kBlock), 0, static_cast<hipStream_t>(stream), ap, n_vec4,
                        reinterpret_cast<float4*>(d_param), reinterpret_cast<const float4*>(d_grad),
                        reinterpret_cast<float4*>(d_exp_avg), reinterpret_cast<float4*>(d_exp_avg_sq), d_visibility);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int gut_mcmc_relocation(void* stream, int32_t n, const float* d_opacities, const float* d_scales, const int32_t* d_ratios,
+                        const float* d_binoms, int32_t n_max, float* d_new_opacities, float* d_new_scales) {
+    if (n <= 0) return 0;
+    if (!d_opacities || !d_scales || !d_ratios || !d_binoms || !d_new_opacities || !d_new_scales || n_max <= 0) return 1;
+    hipLaunchKernelGGL(gut::k_mcmc_relocation, dim3((n + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
+                       static_cast<hipStream_t>(stream), n, d_opacities, d_scales, d_ratios, d_binoms, n_max, d_new_opacities,
+                       d_new_scales);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

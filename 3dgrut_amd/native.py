@@ -96,19 +96,26 @@ class NativeTrainStep:
         self.lr12, self.lr48 = lr12, lr48
         z = lambda c: torch.zeros((n, c), dtype=torch.float32, device=dev)
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
-        self.act = torch.empty((n, 12), dtype=torch.float32, device=dev)
-        self.g12 = torch.empty((n, 12), dtype=torch.float32, device=dev)
         self.fused = bool(fused_sh_adam)
         self.rank = int(rank)
+        self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
+        self.resize_workspace()
+        self.step_id = 0
+
+    def resize_workspace(self):
+        """(Re)allocate the per-step buffers for the current number of Gaussians (called after densification)."""
+        n = self.model.num_gaussians
+        dev = self.model.raw.device
+        self.act = torch.empty((n, 12), dtype=torch.float32, device=dev)
+        self.g12 = torch.empty((n, 12), dtype=torch.float32, device=dev)
         if self.fused:
             # compact exchange: per view only dL/dRGB (12 B per Gaussian) travels; the [N,48] SH gradient is rebuilt
             # inside the fused SH-gradient + Adam kernel (csrc/gut_train.hip: k_sh_adam)
-            self.mrgb = torch.empty((max(1, world_size), n, 3), dtype=torch.float32, device=dev)
-            self.cams = torch.zeros((max(1, world_size), 3), dtype=torch.float32, device=dev)
+            self.mrgb = torch.empty((max(1, self.world_size), n, 3), dtype=torch.float32, device=dev)
+            self.cams = torch.zeros((max(1, self.world_size), 3), dtype=torch.float32, device=dev)
             self.g48 = None
         else:
             self.g48 = torch.empty((n, 48), dtype=torch.float32, device=dev)
-        self.step_id = 0
 
     # ---- pieces ----
     def activate(self):
@@ -158,6 +165,8 @@ class NativeTrainStep:
             self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, compact_radiance_grads=True,
                                   out=(self.g12, self.mrgb[self.rank if w > 1 else 0]))
             cam_local = batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32).contiguous()
+            if self.post_backward_hook is not None:  # per-view statistics, before the exchange (strategy/gs.py:106-115)
+                self.post_backward_hook(self.g12[:, 0:3], cam_local)
             if w > 1:
                 work = allreduce_sum_async(self.g12, w)
                 allgather_rows_(self.mrgb, self.mrgb[self.rank], w)
@@ -181,6 +190,8 @@ class NativeTrainStep:
                 raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
         else:
             self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, out=(self.g12, self.g48))
+            if self.post_backward_hook is not None:
+                self.post_backward_hook(self.g12[:, 0:3], batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32))
             if self.world_size > 1:
                 allreduce_mean_([self.g48, self.g12], self.world_size)
                 if self.selective:

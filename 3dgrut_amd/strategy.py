@@ -1,0 +1,226 @@
+"""Densification / pruning strategies on the native parameter layout ("next" row N3 of SURVEY §8f).
+
+Restates, on the tensors of native.NativeTrainStep (raw [N,12], features [N,48] and their Adam moments), what the
+reference does with per-name nn.Parameters and optimizer-state surgery:
+  * GSStrategy   — threedgrut/strategy/gs.py:60-306 (gradient-norm buffer, clone, split, opacity prune, density
+                   decay / reset), base.py:52-83 (parameter + optimizer-state update rule: moments of new rows are 0);
+  * MCMCStrategy — threedgrut/strategy/mcmc.py:76-197 (relocate dead Gaussians, add new ones, perturb), with the
+                   relocation kernel of src/gaussian_mcmc.cu as HIP (gut_mcmc_relocation).
+All of it is torch tensor surgery that runs every 100-3000 steps, far off the per-step hot path; the only per-step
+piece is update_gradient_buffer.  Data parallel: the per-view norms are accumulated BEFORE the gradient exchange
+(gs.py:106-115 works on per-view gradients) and SUM-reduced at densification time; random splits draw from a
+generator seeded identically on every rank so replicas stay bit-identical.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _capi
+
+POS, DNS, ROT, SCL = slice(0, 3), slice(3, 4), slice(4, 8), slice(8, 11)
+
+
+def _quat_to_rotmat(q):
+    """rows = rotationT rows?  The reference uses quaternion_to_so3 (wxyz, normalised) -> R with columns = axes."""
+    q = torch.nn.functional.normalize(q, dim=1)
+    w, x, y, z = q.unbind(1)
+    return torch.stack([
+        torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], 1),
+        torch.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], 1),
+        torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1)], 1)
+
+
+class _StateOps:
+    """Row surgery on (raw, features) + Adam moments of a NativeTrainStep."""
+
+    def __init__(self, stepper):
+        self.s = stepper
+        self.m = stepper.model
+
+    @property
+    def n(self):
+        return self.m.raw.shape[0]
+
+    def _apply(self, fn_param, fn_moment):
+        s, m = self.s, self.m
+        m.raw = fn_param(m.raw)
+        m.features = fn_param(m.features)
+        s.m12, s.v12 = fn_moment(s.m12), fn_moment(s.v12)
+        s.m48, s.v48 = fn_moment(s.m48), fn_moment(s.v48)
+        s.resize_workspace()
+
+    def keep(self, mask):
+        self._apply(lambda p: p[mask].contiguous(), lambda v: v[mask].contiguous())
+
+    def append(self, raw_new, feat_new):
+        s, m = self.s, self.m
+        k = raw_new.shape[0]
+        m.raw = torch.cat([m.raw, raw_new]).contiguous()
+        m.features = torch.cat([m.features, feat_new]).contiguous()
+        z = lambda v: torch.cat([v, torch.zeros((k, v.shape[1]), dtype=v.dtype, device=v.device)]).contiguous()
+        s.m12, s.v12, s.m48, s.v48 = z(s.m12), z(s.v12), z(s.m48), z(s.v48)
+        s.resize_workspace()
+
+
+class GSStrategy:
+    def __init__(self, stepper, clone_grad_threshold=0.0002, split_grad_threshold=0.0002, relative_size_threshold=0.01,
+                 split_n_gaussians=2, prune_density_threshold=0.005, new_max_density=0.01, density_decay_gamma=0.995, seed=0):
+        self.ops = _StateOps(stepper)
+        self.clone_thr, self.split_thr = clone_grad_threshold, split_grad_threshold
+        self.rel_size, self.split_n = relative_size_threshold, split_n_gaussians
+        self.prune_thr, self.new_max_density, self.decay_gamma = prune_density_threshold, new_max_density, density_decay_gamma
+        self.seed = seed
+        self.reset_buffers()
+
+    def reset_buffers(self):
+        dev = self.ops.m.raw.device
+        self.grad_norm_accum = torch.zeros((self.ops.n, 1), dtype=torch.float32, device=dev)
+        self.grad_norm_denom = torch.zeros((self.ops.n, 1), dtype=torch.int32, device=dev)
+
+    @torch.no_grad()
+    def update_gradient_buffer(self, position_grad, sensor_position):
+        """gs.py:106-115; position_grad = this view's dL/dpositions [N,3] (before any cross-rank exchange)."""
+        mask = (position_grad != 0).any(dim=1)
+        dist = (self.ops.m.raw[:, POS][mask] - sensor_position).norm(dim=1, keepdim=True)
+        self.grad_norm_accum[mask] += torch.norm(position_grad[mask] * dist, dim=-1, keepdim=True) / 2
+        self.grad_norm_denom[mask] += 1
+
+    @torch.no_grad()
+    def densify(self, scene_extent, step=0, world=1):
+        if world > 1:  # per-view statistics are additive over ranks
+            import torch.distributed as dist
+            dist.all_reduce(self.grad_norm_accum)
+            dist.all_reduce(self.grad_norm_denom)
+        g = self.grad_norm_accum / self.grad_norm_denom
+        g[g.isnan()] = 0.0
+        g = g.squeeze(1)
+        self.clone(g, scene_extent)
+        self.split(g, scene_extent, step)
+
+    @torch.no_grad()
+    def clone(self, grad_norm, scene_extent):
+        m = self.ops.m
+        scale_max = torch.exp(m.raw[:, SCL]).max(dim=1).values
+        mask = (grad_norm >= self.clone_thr) & (scale_max <= self.rel_size * scene_extent)
+        self.ops.append(m.raw[mask], m.features[mask])
+        self.reset_buffers()
+        return int(mask.sum())
+
+    @torch.no_grad()
+    def split(self, grad_norm, scene_extent, step=0):
+        m = self.ops.m
+        n0 = self.ops.n
+        padded = torch.zeros(n0, device=m.raw.device)
+        padded[: grad_norm.shape[0]] = grad_norm  # cloned rows appended after the statistics were taken get 0
+        scale = torch.exp(m.raw[:, SCL])
+        mask = (padded >= self.split_thr) & (scale.max(dim=1).values > self.rel_size * scene_extent)
+        k = int(mask.sum())
+        if k:
+            gen = torch.Generator(device=m.raw.device).manual_seed(self.seed * 1_000_003 + step)
+            stds = scale[mask].repeat(self.split_n, 1)
+            samples = torch.randn(stds.shape, generator=gen, device=stds.device) * stds
+            rots = _quat_to_rotmat(m.raw[:, ROT][mask]).repeat(self.split_n, 1, 1)
+            offsets = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1)
+            raw_new = m.raw[mask].repeat(self.split_n, 1)
+            raw_new[:, POS] += offsets
+            raw_new[:, SCL] = torch.log(torch.exp(raw_new[:, SCL]) / (0.8 * self.split_n))
+            feat_new = m.features[mask].repeat(self.split_n, 1)
+            self.ops.keep(~mask)
+            self.ops.append(raw_new, feat_new)
+        self.reset_buffers()
+        return k
+
+    @torch.no_grad()
+    def prune_opacity(self):
+        keep = torch.sigmoid(self.ops.m.raw[:, 3]) >= self.prune_thr
+        self.ops.keep(keep)
+        self.grad_norm_accum, self.grad_norm_denom = self.grad_norm_accum[keep], self.grad_norm_denom[keep]
+        return int((~keep).sum())
+
+    @torch.no_grad()
+    def decay_density(self):
+        d = torch.sigmoid(self.ops.m.raw[:, 3]) * self.decay_gamma
+        self.ops.m.raw[:, 3] = torch.log(d / (1 - d))
+
+    @torch.no_grad()
+    def reset_density(self):
+        cap = math.log(self.new_max_density / (1 - self.new_max_density))
+        self.ops.m.raw[:, 3].clamp_(max=cap)
+        self.ops.s.m12[:, 3] = 0
+        self.ops.s.v12[:, 3] = 0
+
+
+class MCMCStrategy:
+    def __init__(self, stepper, opacity_threshold=0.005, binom_n_max=51, max_n_gaussians=1_000_000, noise_lr=5e5, seed=0):
+        self.ops = _StateOps(stepper)
+        self.opacity_threshold, self.n_max, self.max_n, self.noise_lr, self.seed = opacity_threshold, binom_n_max, max_n_gaussians, noise_lr, seed
+        b = torch.zeros((binom_n_max, binom_n_max), dtype=torch.float32)
+        for n in range(binom_n_max):
+            for k in range(n + 1):
+                b[n, k] = math.comb(n, k)
+        self.binoms = b.to(self.ops.m.raw.device)
+
+    def _relocation(self, dens, scales, ratios):
+        lib = _capi.load()
+        new_d, new_s = torch.empty_like(dens), torch.empty_like(scales)
+        st = torch.cuda.current_stream(dens.device).cuda_stream
+        rc = lib.gut_mcmc_relocation(C.c_void_p(st), dens.shape[0], dens.data_ptr(), scales.data_ptr(), ratios.data_ptr(),
+                                     self.binoms.data_ptr(), self.n_max, new_d.data_ptr(), new_s.data_ptr())
+        if rc:
+            raise RuntimeError(f"[3dgut] mcmc_relocation failed ({rc})")
+        return new_d, new_s
+
+    @torch.no_grad()
+    def sample_new(self, num, valid_idx=None, step=0):
+        """mcmc.py:166-197"""
+        m = self.ops.m
+        dens = torch.sigmoid(m.raw[:, 3])
+        scales = torch.exp(m.raw[:, SCL])
+        if valid_idx is None:
+            valid_idx = torch.arange(dens.shape[0], device=dens.device)
+        gen = torch.Generator(device=dens.device).manual_seed(self.seed * 1_000_003 + step)
+        sampled = valid_idx[torch.multinomial(dens[valid_idx], num, replacement=True, generator=gen)]
+        ratios = (torch.bincount(sampled, minlength=dens.shape[0])[sampled] + 1).clamp_(min=1, max=self.n_max).int()
+        new_d, new_s = self._relocation(dens[sampled].contiguous(), scales[sampled].contiguous(), ratios.contiguous())
+        new_d = new_d.clamp(max=1.0 - torch.finfo(torch.float32).eps, min=self.opacity_threshold)
+        return sampled, torch.log(new_d / (1 - new_d)), torch.log(new_s)
+
+    @torch.no_grad()
+    def relocate(self, step=0):
+        m, s = self.ops.m, self.ops.s
+        dens = torch.sigmoid(m.raw[:, 3])
+        dead = torch.where(dens <= self.opacity_threshold)[0]
+        alive = torch.where(dens > self.opacity_threshold)[0]
+        if dead.numel() and alive.numel():
+            sampled, nd, ns = self.sample_new(dead.numel(), alive, step)
+            m.raw[sampled, 3] = nd
+            m.raw[sampled, 8:11] = ns
+            m.raw[dead] = m.raw[sampled]
+            m.features[dead] = m.features[sampled]
+            for v in (s.m12, s.v12, s.m48, s.v48):
+                v[sampled] = 0
+        return int(dead.numel())
+
+    @torch.no_grad()
+    def add_new(self, step=0):
+        cur = self.ops.n
+        add = max(0, min(self.max_n, int(1.05 * cur)) - cur)
+        if add:
+            sampled, nd, ns = self.sample_new(add, None, step)
+            m = self.ops.m
+            m.raw[sampled, 3] = nd
+            m.raw[sampled, 8:11] = ns
+            self.ops.append(m.raw[sampled], m.features[sampled])
+        return add
+
+    @torch.no_grad()
+    def perturb(self, position_lr, step=0):
+        m = self.ops.m
+        R = _quat_to_rotmat(m.raw[:, ROT])
+        S = torch.diag_embed(torch.exp(m.raw[:, SCL]))
+        cov = R @ S @ S.transpose(1, 2) @ R.transpose(1, 2)
+        dens = torch.sigmoid(m.raw[:, 3:4])
+        gen = torch.Generator(device=m.raw.device).manual_seed(self.seed * 1_000_003 + step + 7)
+        noise = torch.randn(m.raw[:, POS].shape, generator=gen, device=m.raw.device) * (1 / (1 + torch.exp(-100 * ((1 - dens) - 0.995)))) * self.noise_lr * position_lr
+        m.raw[:, POS] += torch.bmm(cov, noise.unsqueeze(-1)).squeeze(-1)

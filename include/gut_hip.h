@@ -216,6 +216,11 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
                      const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
                      const float* d_visibility);
 
+/* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
+ * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */
+int gut_mcmc_relocation(void* stream, int32_t n, const float* d_opacities, const float* d_scales, const int32_t* d_ratios,
+                        const float* d_binoms, int32_t n_max, float* d_new_opacities, float* d_new_scales);
+
 const char* gut_last_error(void);
 int gut_abi_version(void);
 

@@ -83,3 +83,27 @@ def test_native_step_matches_autograd_step(steps, fused):
     assert rel_l2(raw[:, 8:11], ma.scale.detach().cpu().numpy()) <= tol
     feats = torch.cat([ma.features_albedo, ma.features_specular], 1).detach().cpu().numpy()
     assert rel_l2(mn.features.cpu().numpy(), feats) <= tol
+
+
+def test_mcmc_relocation_kernel_matches_formula():
+    """gut_mcmc_relocation vs the closed form of strategy/src/gaussian_mcmc.cu:33-73 evaluated in float64."""
+    import math
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    mn = native.NativeGaussianModel(scenes.scene_c1(300, 2), device=DEV)
+    mc = strategy.MCMCStrategy(native.NativeTrainStep(mn, gut.Tracer({"render": {}})), binom_n_max=51)
+    g = torch.Generator().manual_seed(0)
+    dens = (0.01 + 0.98 * torch.rand(300, generator=g)).cuda()
+    scales = torch.rand((300, 3), generator=g).cuda() + 0.01
+    ratios = torch.randint(1, 52, (300,), generator=g).int().cuda()
+    nd, ns = mc._relocation(dens, scales, ratios)
+    for i in range(0, 300, 7):
+        n = int(ratios[i]); o = float(dens[i])
+        no = 1 - (1 - o) ** (1.0 / n)
+        den = sum(math.comb(a - 1, k) * ((-1) ** k / math.sqrt(k + 1)) * no ** (k + 1) for a in range(1, n + 1) for k in range(a))
+        assert abs(float(nd[i]) - no) <= 2e-6
+        assert abs(float(ns[i, 0]) - o / den * float(scales[i, 0])) <= 2e-4 * abs(o / den * float(scales[i, 0])) + 1e-6
+    # end-to-end: relocation moves dead Gaussians onto live ones and zeroes their moments
+    mn.raw[:40, 3] = -9.0
+    assert mc.relocate(step=1) == 40 and float(torch.sigmoid(mn.raw[:, 3]).min()) > 0.004
+    n0 = mn.num_gaussians
+    assert mc.add_new(step=2) == int(1.05 * n0) - n0 and mn.num_gaussians == int(1.05 * n0)
