@@ -214,8 +214,15 @@ def main():
         dom = max((k for k in ktimes if ktimes[k] > 0), key=lambda k: ktimes[k])
         abytes = algorithmic_bytes(stats, dom, stats["sort_end_bit"])
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same workload only)
+        try:
+            if args.workload == "bicycle_like_6M_1237x822" and not args.num_gaussians:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")))
+                traffic = pmc["kernels"][dom]["hbm_bytes"]
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": abytes,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
                     "mean_launch_ms": ktimes[dom], "launches_averaged": kcount}
         per_kernel = {k: {"ms": ktimes[k], "GBps": (algorithmic_bytes(stats, k, stats["sort_end_bit"]) / (ktimes[k] * 1e-3) / 1e9) if ktimes[k] > 0 else None}
                       for k in ktimes}
