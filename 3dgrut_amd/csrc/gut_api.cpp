@@ -287,7 +287,8 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
     // the reference compiles one kernel variant per render config (setup_3dgut.py:47-70); this library ships
     // the default 3dgut variant and says so instead of silently rendering something else
     if (cfg->particle_kernel_degree != 2) return fail("particle_kernel_degree=%d: only the quadratic (2) kernel of render/3dgut.yaml is built", cfg->particle_kernel_degree);
-    if (cfg->k_buffer_size != 0) return fail("k_buffer_size=%d: only the unsorted (0) variant is built", cfg->k_buffer_size);
+    if (cfg->k_buffer_size < 0 || cfg->k_buffer_size > 16)
+        return fail("k_buffer_size=%d: supported range is 0 (unsorted) .. 16", cfg->k_buffer_size);
     if (cfg->particle_radiance_sph_degree != 3) return fail("particle_radiance_sph_degree=%d: only degree 3 (16 coefficients) is built", cfg->particle_radiance_sph_degree);
     if (cfg->ut_require_all_sigma_points != 0) return fail("ut_require_all_sigma_points must be false (static_assert in threedgut.cuh:73)");
     if (!cfg->enable_hitcounts) return fail("enable_hitcounts=false is not built");
@@ -420,9 +421,16 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     mark(5);
     // with zero intersections the reference returns its freshly initialised outputs (gutRenderer.cu:323-325);
     // running the compositor over empty ranges writes exactly those values
-    gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
-                       h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, d_ray_radiance_density, d_ray_hit_distance,
-                       d_ray_hit_count, h->trav_fwd.as<uint32_t>());
+    if (h->cfg.k_buffer_size > 0) {
+        HIP_TRY(hipMemsetAsync(h->trav_fwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
+        gut::launch_render_sorted(s, v, h->consts, h->cfg.k_buffer_size, d_particle_density, h->feat.as<float>(), d_ray_origin,
+                                  d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m,
+                                  d_ray_radiance_density, d_ray_hit_distance, d_ray_hit_count);
+    } else {
+        gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
+                           h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, d_ray_radiance_density, d_ray_hit_distance,
+                           d_ray_hit_count, h->trav_fwd.as<uint32_t>());
+    }
     mark(6);
     HIP_TRY(hipGetLastError());
     if (total) {
@@ -474,7 +482,6 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
                      float* d_particle_radiance_grad, uint32_t flags) {
     (void)frame_number;
     (void)d_particle_radiance;
-    (void)d_ray_hit_distance;
     if (!h) return fail("gut_trace_bwd: null handle");
     std::lock_guard<std::mutex> lock(h->mu);
     hipStream_t s = static_cast<hipStream_t>(stream_);
@@ -508,7 +515,14 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
     mark(8);
     HIP_TRY(hipMemsetAsync(h->grad16.p, 0, sizeof(float) * 16 * (size_t)n, s));
     mark(9);
-    if (h->m)
+    if (h->m && h->cfg.k_buffer_size > 0) {
+        if (!d_ray_hit_distance) return fail("gut_trace_bwd: the sorted variant needs d_ray_hit_distance");
+        HIP_TRY(hipMemsetAsync(h->trav_bwd.p, 0, sizeof(uint32_t) * (size_t)h->tiles, s));
+        gut::launch_render_sorted_bwd(s, v, h->consts, h->cfg.k_buffer_size, d_particle_density, h->feat.as<float>(), d_ray_origin,
+                                      d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(),
+                                      d_ray_radiance_density, d_ray_hit_distance, d_ray_radiance_density_grad,
+                                      d_ray_hit_distance_grad, h->grad16.as<float>());
+    } else if (h->m)
         gut::launch_render_bwd(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
                                h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_ray_radiance_density,
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),

@@ -74,6 +74,14 @@ void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
                        float* grad16, uint32_t* tile_traversed);
+// sorted (k_buffer_size > 0) compositor variant, gut_render_sorted.hip
+void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
+                          const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
+                          uint32_t num_intersections, float* rgba, float* dist, float* hits);
+void launch_render_sorted_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12,
+                              const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
+                              const uint32_t* sorted_ids, const float* rgba, const float* dist, const float* rgba_grad,
+                              const float* dist_grad, float* grad16);
 void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density12, const uint32_t* tiles_count,
                                 const float* feat, const float* grad16, float* raw_grad12, float* mrgb);
 void launch_stats_reduce(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint32_t t, const uint32_t* trav_fwd,

@@ -816,6 +816,89 @@ void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int 
     if (traversed_out) *traversed_out = traversed_total;
 }
 
+/* K6, sorted variant (k_buffer_size = K > 0): render with a per-ray K-entry hit buffer kept sorted by hit distance —
+ * gutKBufferRenderer.cuh:28-76 (HitParticleKBuffer::insert), :217-292 (evalKBuffer), :108-170 (processHitParticle).
+ * Optionally records, per pixel, the particle ids in the order they were composited (for the autograd check of
+ * the backward: oracle/per_ray_torch.py: composite_ordered). order_ids is [P, max_order], -1 padded. */
+void oracle_render_kbuffer(const OracleParams* prm, const OracleCamera* cam, int W, int H, int K,
+                           const float* density12, const float* feat, const float* ray_ori, const float* ray_dir,
+                           const uint32_t* ranges, const uint32_t* sorted_ids, float* rgba, float* dist, float* hits,
+                           int32_t* order_ids, int32_t* order_count, int max_order) {
+    const PoseSet ps = make_pose_set(cam);
+    const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
+    if (K < 1) K = 1;
+    if (K > 64) K = 64;
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+        for (int py = ty * GUT_TILE; py < (ty + 1) * GUT_TILE && py < H; ++py)
+            for (int px = tx * GUT_TILE; px < (tx + 1) * GUT_TILE && px < W; ++px) {
+                const size_t pix = (size_t)py * W + px;
+                if (order_count) order_count[pix] = 0;
+                Ray ray = make_ray(&ps, ray_ori + 3 * pix, ray_dir + 3 * pix);
+                if (!ray.alive) continue;
+                float T = 1.0f, rgb[3] = {0, 0, 0}, dsum = 0.0f;
+                uint32_t nh = 0;
+                float kb_t[64], kb_a[64]; uint32_t kb_i[64]; int num = 0;
+                for (int i = 0; i < K; ++i) { kb_t[i] = -1.0f; kb_a[i] = 0.0f; kb_i[i] = INVALID_IDX; }
+#define ORACLE_PROCESS(IDX, ALPHA, HITT)                                                    \
+    do {                                                                                     \
+        const float w_ = (ALPHA) * T;                                                        \
+        dsum += (HITT) * w_;                                                                 \
+        T *= (1.0f - (ALPHA));                                                               \
+        if (w_ > 0.0f) {                                                                     \
+            for (int c_ = 0; c_ < 3; ++c_) {                                                 \
+                const float f_ = feat[3 * (size_t)(IDX) + c_];                               \
+                rgb[c_] += (f_ > 0.0f ? f_ : 0.0f) * w_;                                     \
+            }                                                                                \
+            nh++;                                                                            \
+        }                                                                                    \
+        if (order_ids && order_count[pix] < max_order) order_ids[pix * (size_t)max_order + order_count[pix]] = (int32_t)(IDX); \
+        if (order_count) order_count[pix]++;                                                 \
+        if (T < prm->min_transmittance) ray.alive = 0;                                       \
+    } while (0)
+                for (uint32_t k = beg; k < end && ray.alive; ++k) {
+                    const uint32_t id = sorted_ids[k];
+                    if (id == INVALID_IDX) break;
+                    const float* g = density12 + (size_t)id * 12;
+                    float rows[3][3];
+                    quat_to_rows(g + 4, rows);
+                    Hit h;
+                    eval_hit(prm, g, rows, &ray, &h);
+                    if (!((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold))) continue;
+                    const float* s = g + 8;
+                    const float proj = h.grd[0] * -h.gro[0] + h.grd[1] * -h.gro[1] + h.grd[2] * -h.gro[2];
+                    const float v0 = s[0] * h.grd[0] * proj, v1 = s[1] * h.grd[1] * proj, v2 = s[2] * h.grd[2] * proj;
+                    float hit_t = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+                    if (!((hit_t > ray.tmin) && (hit_t < ray.tmax))) continue;
+                    if (num == K) {  /* full: composite the closest stored hit, then free its slot */
+                        ORACLE_PROCESS(kb_i[0], kb_a[0], kb_t[0]);
+                        kb_t[0] = -1.0f;
+                    } else {
+                        num++;
+                    }
+                    /* insert (bubble towards the back while farther than the stored entries) */
+                    float ct = hit_t, ca = h.alpha; uint32_t ci = id;
+                    for (int i = K - 1; i >= 0; --i)
+                        if (ct > kb_t[i]) {
+                            const float tt = kb_t[i], ta = kb_a[i]; const uint32_t ti = kb_i[i];
+                            kb_t[i] = ct; kb_a[i] = ca; kb_i[i] = ci;
+                            ct = tt; ca = ta; ci = ti;
+                        }
+                }
+                for (int i = 0; ray.alive && i < num; ++i) {
+                    const int sl = K - num + i;
+                    ORACLE_PROCESS(kb_i[sl], kb_a[sl], kb_t[sl]);
+                }
+#undef ORACLE_PROCESS
+                rgba[4 * pix] = rgb[0]; rgba[4 * pix + 1] = rgb[1]; rgba[4 * pix + 2] = rgb[2];
+                rgba[4 * pix + 3] = 1.0f - T;
+                dist[pix] = dsum;
+                hits[pix] = (float)nh;
+            }
+    }
+}
+
 /* matmul_bw_quat — common/mathUtils.cuh:468-533 */
 static void matmul_bw_quat(const float p[3], const float g[3], const float q[4], float out[4]) {
     float dm[3][3];

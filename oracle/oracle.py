@@ -149,6 +149,23 @@ def forward(cam: dict, W, H, density12, sph48, ray_ori, ray_dir, sh_degree=3, pa
     return out
 
 
+def render_kbuffer(cam: dict, fwd: dict, K=16, params=None, max_order=0):
+    """Sorted-variant compositing (k_buffer_size=K) on top of a forward() result's tile lists.  Returns rgba, dist, hits and,
+    if max_order > 0, the per-pixel composited particle order (order_ids [P,max_order] int32 -1 padded, order_count [P])."""
+    L = lib()
+    prm = params or default_params()
+    c = make_camera(cam)
+    d12, sph, ro, rd, sh_degree, W, H = fwd["_inputs"]
+    rgba = np.zeros((H, W, 4), np.float32); dist = np.full((H, W, 1), 1e6, np.float32); hits = np.zeros((H, W, 1), np.float32)
+    oc = np.zeros(W * H, np.int32)
+    oi = np.full((W * H, max(1, max_order)), -1, np.int32)
+    if fwd["M"]:
+        L.oracle_render_kbuffer(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), C.c_int(K), _p(d12), _p(fwd["feat"]), _p(ro), _p(rd),
+                                _p(fwd["tile_ranges"]), _p(fwd["sorted_ids"]), _p(rgba), _p(dist), _p(hits),
+                                _p(oi) if max_order else None, _p(oc), C.c_int(max_order))
+    return dict(rgba=rgba, dist=dist, hits=hits, order_ids=oi, order_count=oc)
+
+
 def backward(cam: dict, fwd: dict, rgba_grad, dist_grad, params=None):
     """Backward for a forward() result. Returns (density_grad [N,12] f64, sph_grad [N,48] f64, feat_grad [N,3] f64)."""
     L = lib()

@@ -268,3 +268,36 @@ def render_per_ray(cam, tq, W, H, params, ray_ori, ray_dir, sh_degree=3, dtype=t
         outs.append(torch.cat([rgb, (1 - T)[:, None], dist[:, None], hits[:, None]], dim=1))
     out = torch.cat(outs, 0)
     return out[:, :4], out[:, 4], out[:, 5]
+
+
+def composite_ordered(params, tq, W, H, ray_ori, ray_dir, order_ids, order_count, sh_degree=3, dtype=torch.float64):
+    """Exact (autograd) compositing of each pixel's particles in a GIVEN order — the sorted variant's semantics
+    (k_buffer_size > 0): the reference differentiates it with slang autodiff (gaussianParticles.slang:394-451,
+    shRadiativeParticles.slang:179-207), i.e. true derivatives incl. min(0.99, .) and the hit distance.
+    order_ids [P,L] (-1 padded) comes from the C oracle.  Returns rgba [P,4], dist [P]."""
+    R, t, Rinv, cam_pos = pose_matrices(tq, dtype)
+    pos, rot, scl, dns, sph = (params[k].to(dtype) for k in ("positions", "rotation", "scale", "density", "features"))
+    feat_all = precompute_features(pos, sph, cam_pos, sh_degree).clamp(min=0)
+    rows_all = quat_rows(rot)
+    o, d = world_rays(torch.as_tensor(ray_ori, dtype=dtype), torch.as_tensor(ray_dir, dtype=dtype), Rinv, cam_pos)
+    ids = torch.as_tensor(order_ids.astype("int64"))
+    P, L = ids.shape
+    valid = torch.arange(L)[None, :] < torch.as_tensor(order_count.astype("int64"))[:, None]
+    idc = ids.clamp(min=0)
+    mu, rws, s, sg, ft = pos[idc], rows_all[idc], scl[idc], dns[idc, 0], feat_all[idc]      # [P,L,...]
+    gposc = o[:, None, :] - mu
+    gro = torch.einsum("plij,plj->pli", rws, gposc) / s
+    grdu = torch.einsum("plij,pj->pli", rws, d) / s
+    grd = grdu / grdu.norm(dim=-1, keepdim=True)
+    c = torch.cross(grd, gro, dim=-1)
+    resp = torch.exp(-0.5 * (c * c).sum(-1))
+    alpha = (resp * sg).clamp(max=ALPHA_MAX)
+    alpha = torch.where(valid, alpha, torch.zeros_like(alpha))
+    hit_t = (s * grd * (-(grd * gro).sum(-1))[..., None]).norm(dim=-1)
+    one_m = 1 - alpha
+    T_before = torch.cat([torch.ones(P, 1, dtype=dtype), torch.cumprod(one_m, dim=1)[:, :-1]], dim=1)
+    w = alpha * T_before
+    rgb = (w[..., None] * ft).sum(1)
+    dist = (w * torch.where(valid, hit_t, torch.zeros_like(hit_t))).sum(1)
+    T = one_m.prod(dim=1)
+    return torch.cat([rgb, (1 - T)[:, None]], dim=1), dist

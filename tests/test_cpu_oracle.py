@@ -162,3 +162,22 @@ def test_golden_c1_fixture():
     assert np.abs(o["rgba"][::4, ::4] - g["rgba_sub"]).max() <= 1e-6
     dg, sg, _ = oracle.backward(view["oracle_cam"], o, g["rgba_grad"], np.zeros((128, 128, 1), np.float32))
     assert np.abs(dg.sum(0) - g["density_grad_colsum"]).max() <= 1e-6 * max(1.0, np.abs(g["density_grad_colsum"]).max())
+
+
+@pytest.mark.parametrize("K", [1, 3, 16])
+def test_kbuffer_oracle_matches_ordered_autograd(K):
+    """oracle_render_kbuffer (sorted variant) vs float64 compositing of the order it recorded; K=1 == unsorted."""
+    sc = scenes.scene_c1(300, seed=8)
+    W, H = 40, 32
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, -0.1, -3.0), (0, 0, 0)), fx=44)
+    f = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    kb = oracle.render_kbuffer(view["oracle_cam"], f, K=K, max_order=int(f["hits"].max()) + 32)
+    assert kb["order_count"].max() > 0
+    if K == 1:
+        assert np.abs(kb["rgba"] - f["rgba"]).max() == 0 and np.abs(kb["dist"] - f["dist"]).max() == 0
+    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in sc.items()}
+    rgba, dist = prt.composite_ordered(params, view["tq"], W, H, view["ro"], view["rd"], kb["order_ids"], kb["order_count"])
+    assert np.abs(rgba.numpy().reshape(H, W, 4) - kb["rgba"]).max() <= 3e-5
+    assert np.abs(dist.numpy().reshape(H, W, 1) - kb["dist"]).max() <= 3e-5 * max(1.0, float(kb["dist"].max()))
+    # hit distances composited in non-decreasing order once K covers the local overlap
+    assert np.array_equal(kb["hits"][..., 0].reshape(-1), kb["order_count"].astype(np.float32))
