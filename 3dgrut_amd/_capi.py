@@ -20,7 +20,8 @@ SHUTTER_GLOBAL = 4
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
 
 BUF = dict(tiles_count=0, tiles_offset=1, proj_pos=2, conic_opacity=3, extent=4, depth=5, feat=6,
-           unsorted_keys=7, unsorted_ids=8, sorted_keys=9, sorted_ids=10, tile_ranges=11, grad_scratch=12)
+           unsorted_keys=7, unsorted_ids=8, sorted_keys=9, sorted_ids=10, tile_ranges=11, grad_scratch=12,
+           tile_traversed_fwd=13, tile_traversed_bwd=14)
 
 
 class GutCamera(C.Structure):

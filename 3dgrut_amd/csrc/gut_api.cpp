@@ -121,7 +121,7 @@ struct gut_context {
     // per-M scratch
     DevBuf keys_unsorted, keys_sorted, ids_unsorted, ids_sorted, sort_temp;
     // per-T
-    DevBuf ranges, trav_fwd, trav_bwd;  // per-tile traversal depths (statistics)
+    DevBuf ranges, trav_fwd, trav_bwd, tile_order;  // per-tile traversal depths (statistics)
     DevBuf counters;
     uint32_t* host_count = nullptr;  // pinned
 
@@ -322,7 +322,7 @@ void gut_destroy(gut_handle h) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
-                      &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->counters};
+                      &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     (void)drain_timers(h->fwd_timers);
@@ -367,6 +367,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     HIP_TRY(h->ranges.ensure(sizeof(uint32_t) * 2 * (size_t)tiles));
     HIP_TRY(h->trav_fwd.ensure(sizeof(uint32_t) * (size_t)tiles));
     HIP_TRY(h->trav_bwd.ensure(sizeof(uint32_t) * (size_t)tiles));
+    HIP_TRY(h->tile_order.ensure(sizeof(uint32_t) * (size_t)tiles));
     if (n) HIP_TRY(h->scan_temp.ensure(gut::scan_temp_bytes(n)));
 
     const bool timing = h->cfg.enable_kernel_timings != 0;
@@ -522,11 +523,13 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
                                       d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(),
                                       d_ray_radiance_density, d_ray_hit_distance, d_ray_radiance_density_grad,
                                       d_ray_hit_distance_grad, h->grad16.as<float>());
-    } else if (h->m)
+    } else if (h->m) {
+        gut::launch_tile_order(s, (uint32_t)h->tiles, h->trav_fwd.as<uint32_t>(), h->tile_order.as<uint32_t>());
         gut::launch_render_bwd(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
                                h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_ray_radiance_density,
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
-                               h->trav_bwd.as<uint32_t>());
+                               h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>());
+    }
     mark(10);
     if (flags & GUT_BWD_COMPACT_RADIANCE_GRADS)
         gut::launch_project_bwd_compact(s, n, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
@@ -654,6 +657,10 @@ int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes) {
     case GUT_BUF_GRAD_SCRATCH:
         if (!h->have_backward) return fail("gut_debug_buffer: no backward yet");
         *d_ptr = h->grad16.p; *bytes = 64 * n; break;
+    case GUT_BUF_TILE_TRAVERSED_FWD: *d_ptr = h->trav_fwd.p; *bytes = 4 * t; break;
+    case GUT_BUF_TILE_TRAVERSED_BWD:
+        if (!h->have_backward) return fail("gut_debug_buffer: no backward yet");
+        *d_ptr = h->trav_bwd.p; *bytes = 4 * t; break;
     default: return fail("gut_debug_buffer: unknown buffer %d", which);
     }
     return 0;

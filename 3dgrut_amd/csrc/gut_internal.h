@@ -73,7 +73,8 @@ void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, co
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, uint32_t* tile_traversed);
+                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order);
+void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order);
 // sorted (k_buffer_size > 0) compositor variant, gut_render_sorted.hip
 void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
                           const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,

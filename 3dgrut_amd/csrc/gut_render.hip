@@ -264,13 +264,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
                                                            const float4* __restrict__ rgba,
                                                            const float4* __restrict__ rgba_grad,
                                                            const float* __restrict__ dist_grad, float* __restrict__ grad16,
-                                                           uint32_t* __restrict__ tile_traversed) {
+                                                           uint32_t* __restrict__ tile_traversed,
+                                                           const uint32_t* __restrict__ tile_order) {
     constexpr int W = AccLayout<kDistGrad>::kW;
     __shared__ FwdEntry stage[kBlock];
     __shared__ float acc[kBlock * W];
     __shared__ uint32_t s_deepest, s_first_invalid;
 
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // deepest tiles are dispatched first
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + (int)(tid & 15);
@@ -538,17 +539,51 @@ void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, co
                        reinterpret_cast<float4*>(rgba), dist, hits, tile_traversed);
 }
 
+// Launch order for the backward: tiles by decreasing forward traversal depth (the backward walks exactly as deep),
+// longest-processing-time-first, so the few deep tiles do not become the tail of the grid.  One workgroup: 256
+// linear buckets between 0 and the deepest tile, counting sort in LDS; the order inside a bucket is irrelevant.
+__global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const uint32_t* __restrict__ traversed,
+                                                     uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_max, s_hist[256], s_base[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_max = 0;
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (uint32_t t = tid; t < tiles; t += 1024) mx = max(mx, traversed[t]);
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint32_t width = s_max / 256 + 1;
+    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&s_hist[255 - min(255u, traversed[t] / width)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 256; ++b) {
+            s_base[b] = run;
+            run += s_hist[b];
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < tiles; t += 1024) order[atomicAdd(&s_base[255 - min(255u, traversed[t] / width)], 1u)] = t;
+}
+
+void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order) {
+    if (tiles == 0) return;
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tiles, traversed, order);
+}
+
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, uint32_t* tile_traversed) {
+                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     auto kern = dist_grad != nullptr ? k_render_backward<true> : k_render_backward<false>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
                        reinterpret_cast<const float4*>(rgba), reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
-                       tile_traversed);
+                       tile_traversed, tile_order);
 }
 
 }  // namespace gut

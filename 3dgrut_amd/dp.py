@@ -5,8 +5,18 @@ gradients are additive over views, so one exchange per optimiser step: SUM all-r
 GPU box, gloo in the CPU tests) followed by 1/world, which makes the step's loss the mean over its views.
 No other collective is on the path; the visibility mask is MAX-reduced only when SelectiveAdam is on.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _skip(world: int) -> bool:
+    """World 1 needs no exchange.  GUT_DP_FORCE_COLLECTIVES=1 (with an initialised process group) still issues every
+    collective so the RCCL call sequence can be exercised on a one-GPU box (bench.py --force-exchange)."""
+    if world > 1:
+        return False
+    return not (os.environ.get("GUT_DP_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized())
 
 
 def _stage_on_cpu(t, group=None) -> bool:
@@ -22,7 +32,7 @@ def view_index(step: int, rank: int, world: int, n_views: int) -> int:
 
 def allreduce_mean_(tensors, world: int, group=None):
     """In-place mean over ranks of every tensor in `tensors` (largest first so the big SH message starts early)."""
-    if world <= 1:
+    if _skip(world):
         return
     inv = 1.0 / world
     if any(_stage_on_cpu(t, group) for t in tensors):
@@ -40,7 +50,7 @@ def allreduce_mean_(tensors, world: int, group=None):
 
 
 def allreduce_max_(tensor, world: int, group=None):
-    if world > 1:
+    if not _skip(world):
         if _stage_on_cpu(tensor, group):
             h = tensor.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
@@ -54,7 +64,7 @@ def allreduce_sum_async(tensor, world: int, group=None):
     class _Done:
         def wait(self):
             return None
-    if world <= 1:
+    if _skip(world):
         return _Done()
     if _stage_on_cpu(tensor, group):
         h = tensor.cpu()
@@ -66,7 +76,7 @@ def allreduce_sum_async(tensor, world: int, group=None):
 
 def allgather_rows_(out, local, world: int, group=None):
     """out[world, ...] <- every rank's `local` tensor (rank order).  out[rank] may alias local."""
-    if world <= 1:
+    if _skip(world):
         if out[0].data_ptr() != local.data_ptr():
             out[0].copy_(local)
         return

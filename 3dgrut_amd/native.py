@@ -13,6 +13,7 @@ This removes the ~20 Gaussian-sized elementwise/cat/split passes torch makes per
 The math is the same: tests compare one step of both paths (tests/test_gpu_native.py).
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -98,6 +99,7 @@ class NativeTrainStep:
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
         self.fused = bool(fused_sh_adam)
         self.rank = int(rank)
+        self.force_exchange = os.environ.get("GUT_DP_FORCE_COLLECTIVES") == "1"  # see dp._skip
         self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
         self.resize_workspace()
         self.step_id = 0
@@ -167,7 +169,7 @@ class NativeTrainStep:
             cam_local = batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32).contiguous()
             if self.post_backward_hook is not None:  # per-view statistics, before the exchange (strategy/gs.py:106-115)
                 self.post_backward_hook(self.g12[:, 0:3], cam_local)
-            if w > 1:
+            if w > 1 or self.force_exchange:
                 work = allreduce_sum_async(self.g12, w)
                 allgather_rows_(self.mrgb, self.mrgb[self.rank], w)
                 allgather_rows_(self.cams, cam_local, w)
@@ -192,7 +194,7 @@ class NativeTrainStep:
             self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, out=(self.g12, self.g48))
             if self.post_backward_hook is not None:
                 self.post_backward_hook(self.g12[:, 0:3], batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32))
-            if self.world_size > 1:
+            if self.world_size > 1 or self.force_exchange:
                 allreduce_mean_([self.g48, self.g12], self.world_size)
                 if self.selective:
                     allreduce_max_(vis, self.world_size)

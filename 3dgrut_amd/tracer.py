@@ -268,7 +268,8 @@ class SplatRaster:
         ptr, nbytes = C.c_void_p(), C.c_size_t()
         _capi.check(self._lib.gut_debug_buffer(self._handle, _capi.BUF[name], C.byref(ptr), C.byref(nbytes)), "debug_buffer")
         dt = {"tiles_count": torch.int32, "tiles_offset": torch.int32, "unsorted_ids": torch.int32,
-              "sorted_ids": torch.int32, "tile_ranges": torch.int32, "unsorted_keys": torch.int64,
+              "sorted_ids": torch.int32, "tile_ranges": torch.int32, "tile_traversed_fwd": torch.int32,
+              "tile_traversed_bwd": torch.int32, "unsorted_keys": torch.int64,
               "sorted_keys": torch.int64}.get(name, torch.float32)
         n = nbytes.value // (8 if dt == torch.int64 else 4)
         dev = torch.device("cuda", self.device_index) if device is None else device

@@ -120,6 +120,9 @@ def main():
                     help="native: fused HIP activation/Adam around the renderer; autograd: torch.autograd + torch.optim.Adam")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="native trainer: materialise the [N,48] SH gradient and all-reduce it (default: compact exchange + fused SH-grad/Adam)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N=1 only: initialise RCCL with world size 1 and issue the data-parallel collectives anyway "
+                         "(exercises the N>1 call sequence on a one-GPU box; the number is NOT a bench line)")
     ap.add_argument("--selective-adam", action="store_true", help="visibility-masked Adam (reference SelectiveAdam)")
     args = ap.parse_args()
 
@@ -132,7 +135,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if args.force_exchange and world == 1:
+        os.environ["GUT_DP_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29531")
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -105,7 +105,9 @@ enum {
     GUT_BUF_SORTED_KEYS = 9,   /* u64 [M] */
     GUT_BUF_SORTED_IDS = 10,   /* u32 [M] */
     GUT_BUF_TILE_RANGES = 11,  /* u32 [T,2] */
-    GUT_BUF_GRAD_SCRATCH = 12  /* f32 [N,16] per-Gaussian gradient rows of the last trace_bwd */
+    GUT_BUF_GRAD_SCRATCH = 12, /* f32 [N,16] per-Gaussian gradient rows of the last trace_bwd */
+    GUT_BUF_TILE_TRAVERSED_FWD = 13, /* u32 [T] list entries each tile walked before all its rays terminated */
+    GUT_BUF_TILE_TRAVERSED_BWD = 14  /* u32 [T] same, last trace_bwd */
 };
 
 /* fills *cfg with the reference defaults (configs/render/3dgut.yaml + 3dgrt.yaml) */
