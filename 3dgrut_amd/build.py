@@ -18,8 +18,8 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 # (source, extra flags).  gut_project / gut_api carry the bit-exact numerics contract -> no FMA contraction.
 UNITS = [
     ("gut_project.hip", ["-ffp-contract=off"]),
-    ("gut_render.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics"]),
-    ("gut_render_sorted.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics"]),
+    ("gut_render.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"]),
+    ("gut_render_sorted.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"]),
     ("gut_sort.hip", ["-Wno-unused-parameter"]),
     ("gut_ssim.hip", ["-ffp-contract=fast"]),
     ("gut_train.hip", ["-ffp-contract=fast"]),

@@ -114,12 +114,8 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
         // entries of this chunk that are real particles (padding ids end the list for everyone, gutKBufferRenderer.cuh:256-259)
         const uint32_t cnt = min(min((uint32_t)kBlock, total - base), s_first_invalid);
         // software pipeline: the parameters of entry j+1 are fetched from LDS while entry j is evaluated
-        float4 ms = stage[0].mu_sigma, m0 = stage[0].m0, m1 = stage[0].m1, m2 = stage[0].m2;
-        for (uint32_t j = 0; j < cnt; ++j) {
-            if (__ballot(alive) == 0ull) break;  // wave-uniform
-            const float4 cs = ms, c0 = m0, c1 = m1, c2 = m2;
-            const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
-            ms = stage[jn].mu_sigma; m0 = stage[jn].m0; m1 = stage[jn].m1; m2 = stage[jn].m2;
+        auto entry = [&](const float4& cs, const float4& c0, const float4& c1, const float4& c2, const uint32_t j)
+                         __attribute__((always_inline)) {
             if (alive) {
                 consumed = base + j + 1;
                 float o0 = cs.x, o1 = cs.y, o2 = cs.z;
@@ -158,6 +154,29 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                         }
                     }
                 }
+            }
+        };
+        // software pipeline, unrolled by two (two alternating register sets, no per-iteration moves): the parameters of
+        // entry j+1 are fetched from LDS while entry j is evaluated
+        {
+            float4 a0 = stage[0].mu_sigma, a1 = stage[0].m0, a2 = stage[0].m1, a3 = stage[0].m2;
+            float4 b0, b1, b2, b3;
+            uint32_t j = 0;
+            while (j < cnt) {
+                if (__ballot(alive) == 0ull) break;  // wave-uniform
+                {
+                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
+                    b0 = stage[jn].mu_sigma; b1 = stage[jn].m0; b2 = stage[jn].m1; b3 = stage[jn].m2;
+                }
+                entry(a0, a1, a2, a3, j);
+                if (++j >= cnt) break;
+                if (__ballot(alive) == 0ull) break;
+                {
+                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
+                    a0 = stage[jn].mu_sigma; a1 = stage[jn].m0; a2 = stage[jn].m1; a3 = stage[jn].m2;
+                }
+                entry(b0, b1, b2, b3, j);
+                ++j;
             }
         }
         if (cnt < min((uint32_t)kBlock, total - base)) alive = false;  // list ended at a padding entry
@@ -206,43 +225,69 @@ __device__ __forceinline__ float dpp_mov(float oldv, float v) {
                                                                  kCtrl, kRowMask, kBankMask, false));
 }
 
-// Sums each of the 16 values of v[] over the 64 lanes.  On return lane 48+k (k = 0..15) holds in its return value
-// the wave total of v[slot(k)], slot(k) = 8*(k&1) + 4*((k>>1)&1) + 2*((k>>2)&1) + ((k>>3)&1).
-__device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], uint32_t lane) {
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    float a[8], b[4], c[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // partner = lane ^ 1 (quad_perm [1,0,3,2])
-        const float keep = b0 ? v[8 + i] : v[i];
-        const float send = b0 ? v[i] : v[8 + i];
-        a[i] = keep + dpp_mov<0xB1>(0.f, send);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {  // partner = lane ^ 2 (quad_perm [2,3,0,1])
-        const float keep = b1 ? a[4 + i] : a[i];
-        const float send = b1 ? a[i] : a[4 + i];
-        b[i] = keep + dpp_mov<0x4E>(0.f, send);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {  // partner = lane ^ 4: row_shl:4 feeds banks 0,2 ; row_shr:4 feeds banks 1,3
-        const float keep = b2 ? b[2 + i] : b[i];
-        const float send = b2 ? b[i] : b[2 + i];
-        float recv = dpp_mov<0x104, 0xF, 0x5>(0.f, send);
-        recv = dpp_mov<0x114, 0xF, 0xA>(recv, send);
-        c[i] = keep + recv;
-    }
-    float r;
-    {  // partner = lane ^ 8 (row_ror:8)
-        const float keep = b3 ? c[1] : c[0];
-        const float send = b3 ? c[0] : c[1];
-        r = keep + dpp_mov<0x128>(0.f, send);
-    }
-    return r;  // lane l: total over its 16-lane row of v[slot(l & 15)]; the 4 rows are combined by the LDS atomic
+// Sums each of the 16 values of v[] over the 64 lanes of the wave ("transpose-reduce": every exchange step halves the
+// number of live registers).  gfx950's half-wave / row swaps do the first two steps without any select:
+//   v_permlane32_swap a, b : a = [a.lanes0-31 | b.lanes0-31],  b = [a.lanes32-63 | b.lanes32-63]  -> a + b folds the halves
+//   v_permlane16_swap a, b : a = [a.row0, b.row0, a.row2, b.row2], b = [a.row1, b.row1, a.row3, b.row3] (rows of 16 lanes)
+// after which row r holds, per lane column, the 4-row partial sums of v[i + 4r] in register i (i = 0..3); two
+// select+DPP steps inside each row and two row rotations finish it.  35 VALU ops for 16 values.
+// On return every lane holds the wave total of v[reduce_slot(lane)]; lanes with (lane & 12) == 0 are the 16 distinct ones.
+// (inline asm rather than __builtin_amdgcn_permlane{32,16}_swap: with ROCm 7.2's hipcc, adding the two results of the
+//  builtin folds to r[0] + r[0] at -O3.  The leading s_nop 1 covers the "VALU write -> v_permlane*_swap read" hazard
+//  (2 wait states) for the whole group: every operand is written before the group starts.)
+__device__ __forceinline__ void permlane32_swap_x8(float (&a)[16]) {
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %8\n\t"
+        "v_permlane32_swap_b32 %1, %9\n\t"
+        "v_permlane32_swap_b32 %2, %10\n\t"
+        "v_permlane32_swap_b32 %3, %11\n\t"
+        "v_permlane32_swap_b32 %4, %12\n\t"
+        "v_permlane32_swap_b32 %5, %13\n\t"
+        "v_permlane32_swap_b32 %6, %14\n\t"
+        "v_permlane32_swap_b32 %7, %15"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+          "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+__device__ __forceinline__ void permlane16_swap_x4(float (&a)[8]) {
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %4\n\t"
+        "v_permlane16_swap_b32 %1, %5\n\t"
+        "v_permlane16_swap_b32 %2, %6\n\t"
+        "v_permlane16_swap_b32 %3, %7"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
 }
 
-__device__ __forceinline__ uint32_t reduce_slot(uint32_t lane) {
-    return 8u * (lane & 1u) + 4u * ((lane >> 1) & 1u) + 2u * ((lane >> 2) & 1u) + ((lane >> 3) & 1u);
+__device__ __forceinline__ float wave_transpose_reduce16(const float (&v)[16], uint32_t lane) {
+    float t[16], x[8], y[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = v[i];
+    permlane32_swap_x8(t);  // pairs (v[i], v[i+8])
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = t[i] + t[i + 8];
+    permlane16_swap_x4(x);  // pairs (x[i], x[i+4])
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = x[i] + x[i + 4];
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float z[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // partner = lane ^ 1 (quad_perm [1,0,3,2]): keep y[2i + b0]
+        const float keep = b0 ? y[2 * i + 1] : y[2 * i];
+        const float send = b0 ? y[2 * i] : y[2 * i + 1];
+        z[i] = keep + dpp_mov<0xB1>(0.f, send);
+    }
+    float w;
+    {  // partner = lane ^ 2 (quad_perm [2,3,0,1]): keep z[b1]
+        const float keep = b1 ? z[1] : z[0];
+        const float send = b1 ? z[0] : z[1];
+        w = keep + dpp_mov<0x4E>(0.f, send);
+    }
+    w += dpp_mov<0x124>(0.f, w);  // row_ror:4
+    w += dpp_mov<0x128>(0.f, w);  // row_ror:8 -> all four quads of the row hold the row's totals
+    return w;
 }
+
+// value index whose wave total wave_transpose_reduce16 leaves in this lane
+__device__ __forceinline__ uint32_t reduce_slot(uint32_t lane) { return (lane & 1u) + 2u * ((lane >> 1) & 1u) + 4u * (lane >> 4); }
 
 constexpr int kGradRow = 16;  // floats per global gradient row: pos3, density, quat4, scale3, rgb3, pad2
 
@@ -300,13 +345,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
         if (kDistGrad) gd = dist_grad[pix];
     }
 
+    // out-of-image lanes (ragged right/bottom tiles) never hit, but they run the gradient arithmetic with zero weights
+    // once any lane of their wave hits: give them a unit direction so that arithmetic stays finite
+    const float dir2 = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+    const float ori1 = fabsf(ray.ex) + fabsf(ray.ey) + fabsf(ray.ez);
+    const bool usable = inside && (dir2 > 0.0f) && (dir2 < 3.0e38f) && (ori1 < 3.0e38f);  // false for NaN / inf / zero rays
+    const float rdx = usable ? ray.dx : 0.0f, rdy = usable ? ray.dy : 0.0f, rdz = usable ? ray.dz : 1.0f;
+    const float rex = usable ? ray.ex : 0.0f, rey = usable ? ray.ey : 0.0f, rez = usable ? ray.ez : 0.0f;
+
     const uint2 range = ranges[tile];
     const uint32_t total = range.y - range.x;
     const uint32_t my_slot = reduce_slot(lane);
-    bool alive = ray.valid;
+    bool alive = ray.valid && usable;
     float T = 1.0f, rr = 0.f, rg = 0.f, rb = 0.f;  // running transmittance / radiance
     uint32_t consumed = 0;
-
     for (uint32_t base = 0; base < total; base += kBlock) {
         if (!__syncthreads_or(alive ? 1 : 0)) break;
         {
@@ -339,120 +391,136 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
 
         const uint32_t cnt_all = min((uint32_t)kBlock, total - base);
         const uint32_t cnt = min(cnt_all, s_first_invalid);  // padding ids end the list for everyone
-        float4 nms = stage[0].mu_sigma, nm0 = stage[0].m0, nm1 = stage[0].m1, nm2 = stage[0].m2;
-        for (uint32_t j = 0; j < cnt; ++j) {
-            if (__ballot(alive) == 0ull) break;
-            // software pipeline: entry j+1 is fetched from LDS while entry j is evaluated
-            const float4 ms = nms, m0 = nm0, m1 = nm1, m2 = nm2;
-            const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
-            nms = stage[jn].mu_sigma; nm0 = stage[jn].m0; nm1 = stage[jn].m1; nm2 = stage[jn].m2;
+        // one list entry for this wave's 64 pixels
+        auto entry = [&](const float4& ms, const float4& m0, const float4& m1, const float4& m2, const uint32_t j)
+                         __attribute__((always_inline)) {
+            if (alive) consumed = base + j + 1;
+            float o0 = ms.x, o1 = ms.y, o2 = ms.z;
+            if (!centred) {
+                o0 += m0.x * rex + m0.y * rey + m0.z * rez;
+                o1 += m1.x * rex + m1.y * rey + m1.z * rez;
+                o2 += m2.x * rex + m2.y * rey + m2.z * rez;
+            }
+            const float u0 = m0.x * rdx + m0.y * rdy + m0.z * rdz;
+            const float u1 = m1.x * rdx + m1.y * rdy + m1.z * rdz;
+            const float u2 = m2.x * rdx + m2.y * rdy + m2.z * rdz;
+            const float c0 = u1 * o2 - u2 * o1, c1 = u2 * o0 - u0 * o2, c2 = u0 * o1 - u1 * o0;
+            const float l2 = u0 * u0 + u1 * u1 + u2 * u2;
+            const float il2 = fast_rcp(l2);
+            const float d2 = (c0 * c0 + c1 * c1 + c2 * c2) * il2;
+            const float resp = fast_exp(-0.5f * d2);
+            const float a0 = resp * ms.w;
+            const float alpha = fminf(c.max_alpha, a0);
+            // NB: no tmin/tmax test in the backward
+            const bool hit = alive && (d2 < c.max_d2) && (resp > c.min_response) && (alpha > c.alpha_threshold);
+            if (__ballot(hit) == 0ull) return;  // wave-uniform: no lane of this wave hit entry j
+
+            // From here every lane runs the same instruction stream; lanes that did not hit carry alpha = 0 and a zero
+            // upstream factor, which makes all 16 partial derivatives exactly zero without per-value selects (all their
+            // intermediates are finite: rays of out-of-image lanes were given a unit direction above).
+            const float am = hit ? alpha : 0.0f;
+            const float rm = hit ? resp : 0.0f;
             float g[16];
             float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;  // direct scale terms (kDistGrad only)
-            bool hit = false;
-            if (alive) {
-                consumed = base + j + 1;
-                float o0 = ms.x, o1 = ms.y, o2 = ms.z;
-                if (!centred) {
-                    o0 += m0.x * ray.ex + m0.y * ray.ey + m0.z * ray.ez;
-                    o1 += m1.x * ray.ex + m1.y * ray.ey + m1.z * ray.ez;
-                    o2 += m2.x * ray.ex + m2.y * ray.ey + m2.z * ray.ez;
+            const float4 fid = stage[j].feat_id;
+            const float w = am * T;
+            const float Tn = (1.0f - am) * T;
+            const float t = (u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (u.o)/|u|^2
+            const float q0 = o0 - t * u0, q1 = o1 - t * u1, q2 = o2 - t * u2;  // o_perp
+            float ga_hit = 0.f;
+            float k0 = 0.f, k1 = 0.f, k2 = 0.f, d0 = 0.f, d1 = 0.f, d2n = 0.f, il = 0.f;
+            if (kDistGrad) {
+                // hit-distance terms (residualHitT == 0: quirk 1 of SURVEY §8a); grd = u/|u|
+                il = fast_rsq(l2);
+                d0 = u0 * il; d1 = u1 * il; d2n = u2 * il;
+                const float proj = -(d0 * o0 + d1 * o1 + d2n * o2);
+                const float s0 = m0.w * d0 * proj, s1 = m1.w * d1 * proj, s2 = m2.w * d2n * proj;  // grds
+                const float gsq = s0 * s0 + s1 * s1 + s2 * s2;
+                const float gdist = sqrtf(gsq);
+                ga_hit = gdist * T * gd;
+                if (gsq > 0.0f) {
+                    const float kk = (w / gdist) * gd;
+                    k0 = s0 * kk; k1 = s1 * kk; k2 = s2 * kk;  // grdsRayHitGrd
                 }
-                const float u0 = m0.x * ray.dx + m0.y * ray.dy + m0.z * ray.dz;
-                const float u1 = m1.x * ray.dx + m1.y * ray.dy + m1.z * ray.dz;
-                const float u2 = m2.x * ray.dx + m2.y * ray.dy + m2.z * ray.dz;
-                const float c0 = u1 * o2 - u2 * o1, c1 = u2 * o0 - u0 * o2, c2 = u0 * o1 - u1 * o0;
-                const float l2 = u0 * u0 + u1 * u1 + u2 * u2;
-                const float il2 = fast_rcp(l2);
-                const float d2 = (c0 * c0 + c1 * c1 + c2 * c2) * il2;
-                if (d2 < c.max_d2) {
-                    const float resp = fast_exp(-0.5f * d2);
-                    const float a0 = resp * ms.w;
-                    const float alpha = fminf(c.max_alpha, a0);
-                    if ((resp > c.min_response) && (alpha > c.alpha_threshold)) {  // NB: no tmin/tmax test in the backward
-                        hit = true;
-                        const float4 fid = stage[j].feat_id;
-                        const float w = alpha * T;
-                        const float Tn = (1.0f - alpha) * T;
-                        const float t = (u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (u.o)/|u|^2
-                        const float q0 = o0 - t * u0, q1 = o1 - t * u1, q2 = o2 - t * u2;  // o_perp
-                        float ga_hit = 0.f;
-                        float k0 = 0.f, k1 = 0.f, k2 = 0.f, d0 = 0.f, d1 = 0.f, d2n = 0.f, il = 0.f;
-                        if (kDistGrad) {
-                            // hit-distance terms (residualHitT == 0: quirk 1 of SURVEY §8a); grd = u/|u|
-                            il = fast_rsq(l2);
-                            d0 = u0 * il; d1 = u1 * il; d2n = u2 * il;
-                            const float proj = -(d0 * o0 + d1 * o1 + d2n * o2);
-                            const float s0 = m0.w * d0 * proj, s1 = m1.w * d1 * proj, s2 = m2.w * d2n * proj;  // grds
-                            const float gsq = s0 * s0 + s1 * s1 + s2 * s2;
-                            const float gdist = sqrtf(gsq);
-                            ga_hit = gdist * T * gd;
-                            if (gsq > 0.0f) {
-                                const float kk = (w / gdist) * gd;
-                                k0 = s0 * kk; k1 = s1 * kk; k2 = s2 * kk;  // grdsRayHitGrd
-                            }
-                            gs0 = d0 * proj * k0; gs1 = d1 * proj * k1; gs2 = d2n * proj * k2;  // gsclRayHitGrd
-                        }
-                        const float res_T = alpha < 0.999999f ? T_final * fast_rcp(1.0f - alpha) : T;
-                        const float ga_dns = res_T * -Tg;
-                        g[13] = gr * w; g[14] = gg * w; g[15] = gb * w;
-                        rr += w * fid.x; rg += w * fid.y; rb += w * fid.z;
-                        float e0 = 0.f, e1 = 0.f, e2 = 0.f;  // residual radiance behind this particle
-                        if (!(Tn <= c.min_transmittance)) {
-                            const float iT = fast_rcp(Tn);
-                            e0 = fmaxf((fr - rr) * iT, 0.0f);
-                            e1 = fmaxf((fg - rg) * iT, 0.0f);
-                            e2 = fmaxf((fb - rb) * iT, 0.0f);
-                        }
-                        const float G = ga_hit + ga_dns + T * ((fid.x - e0) * gr + (fid.y - e1) * gg + (fid.z - e2) * gb);
-                        g[12] = resp * G;                      // d density
-                        const float g_d2x2 = -a0 * G;          // 2 * dL/d(d2) = 2 * (-1/2 resp sigma G)
-                        float h0 = g_d2x2 * q0, h1 = g_d2x2 * q1, h2 = g_d2x2 * q2;  // dL/do
-                        if (!kDistGrad) {
-                            // m = (ray_o - mu) - t d = (e - t d) + (sensor_pos - mu); the second, per-entry constant part is
-                            // added in the epilogue as H (x) (sensor_pos - mu)
-                            const float n0 = ray.ex - t * ray.dx, n1 = ray.ey - t * ray.dy, n2 = ray.ez - t * ray.dz;
-                            g[0] = h0 * n0; g[1] = h0 * n1; g[2] = h0 * n2;
-                            g[3] = h1 * n0; g[4] = h1 * n1; g[5] = h1 * n2;
-                            g[6] = h2 * n0; g[7] = h2 * n1; g[8] = h2 * n2;
-                        } else {
-                            float v0 = -t * h0, v1 = -t * h1, v2 = -t * h2;  // dL/du from the response term
-                            // reference's diagonal hit-distance terms: d/d(gro) and d/d(grd) (gaussianParticles.cuh:559-567)
-                            const float x0 = d0 * o0, x1 = d1 * o1, x2 = d2n * o2;
-                            h0 += -m0.w * d0 * d0 * k0;
-                            h1 += -m1.w * d1 * d1 * k1;
-                            h2 += -m2.w * d2n * d2n * k2;
-                            const float hd0 = -m0.w * (2.0f * x0 + x1 + x2) * k0;
-                            const float hd1 = -m1.w * (x0 + 2.0f * x1 + x2) * k1;
-                            const float hd2 = -m2.w * (x0 + x1 + 2.0f * x2) * k2;
-                            const float dot = hd0 * d0 + hd1 * d1 + hd2 * d2n;  // safe_normalize_bw
-                            v0 += il * (hd0 - d0 * dot);
-                            v1 += il * (hd1 - d1 * dot);
-                            v2 += il * (hd2 - d2n * dot);
-                            g[0] = h0 * ray.ex + v0 * ray.dx; g[1] = h0 * ray.ey + v0 * ray.dy; g[2] = h0 * ray.ez + v0 * ray.dz;
-                            g[3] = h1 * ray.ex + v1 * ray.dx; g[4] = h1 * ray.ey + v1 * ray.dy; g[5] = h1 * ray.ez + v1 * ray.dz;
-                            g[6] = h2 * ray.ex + v2 * ray.dx; g[7] = h2 * ray.ey + v2 * ray.dy; g[8] = h2 * ray.ez + v2 * ray.dz;
-                        }
-                        g[9] = h0; g[10] = h1; g[11] = h2;
-                        T = Tn;
-                        if (T < c.min_transmittance) alive = false;
-                    }
+                gs0 = d0 * proj * k0; gs1 = d1 * proj * k1; gs2 = d2n * proj * k2;  // gsclRayHitGrd
+            }
+            const float res_T = am < 0.999999f ? T_final * fast_rcp(1.0f - am) : T;
+            const float ga_dns = res_T * -Tg;
+            g[13] = gr * w; g[14] = gg * w; g[15] = gb * w;
+            rr += w * fid.x; rg += w * fid.y; rb += w * fid.z;
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f;  // residual radiance behind this particle
+            if (!(Tn <= c.min_transmittance)) {
+                const float iT = fast_rcp(Tn);
+                e0 = fmaxf((fr - rr) * iT, 0.0f);
+                e1 = fmaxf((fg - rg) * iT, 0.0f);
+                e2 = fmaxf((fb - rb) * iT, 0.0f);
+            }
+            const float Gall = ga_hit + ga_dns + T * ((fid.x - e0) * gr + (fid.y - e1) * gg + (fid.z - e2) * gb);
+            const float G = hit ? Gall : 0.0f;
+            g[12] = rm * G;                            // d density
+            const float g_d2x2 = -(rm * ms.w) * G;     // 2 * dL/d(d2) = 2 * (-1/2 resp sigma G)
+            float h0 = g_d2x2 * q0, h1 = g_d2x2 * q1, h2 = g_d2x2 * q2;  // dL/do
+            if (!kDistGrad) {
+                // m = (ray_o - mu) - t d = (e - t d) + (sensor_pos - mu); the second, per-entry constant part is
+                // added in the epilogue as H (x) (sensor_pos - mu)
+                const float n0 = rex - t * rdx, n1 = rey - t * rdy, n2 = rez - t * rdz;
+                g[0] = h0 * n0; g[1] = h0 * n1; g[2] = h0 * n2;
+                g[3] = h1 * n0; g[4] = h1 * n1; g[5] = h1 * n2;
+                g[6] = h2 * n0; g[7] = h2 * n1; g[8] = h2 * n2;
+            } else {
+                float v0 = -t * h0, v1 = -t * h1, v2 = -t * h2;  // dL/du from the response term
+                // reference's diagonal hit-distance terms: d/d(gro) and d/d(grd) (gaussianParticles.cuh:559-567)
+                const float x0 = d0 * o0, x1 = d1 * o1, x2 = d2n * o2;
+                h0 += -m0.w * d0 * d0 * k0;
+                h1 += -m1.w * d1 * d1 * k1;
+                h2 += -m2.w * d2n * d2n * k2;
+                const float hd0 = -m0.w * (2.0f * x0 + x1 + x2) * k0;
+                const float hd1 = -m1.w * (x0 + 2.0f * x1 + x2) * k1;
+                const float hd2 = -m2.w * (x0 + x1 + 2.0f * x2) * k2;
+                const float dot = hd0 * d0 + hd1 * d1 + hd2 * d2n;  // safe_normalize_bw
+                v0 += il * (hd0 - d0 * dot);
+                v1 += il * (hd1 - d1 * dot);
+                v2 += il * (hd2 - d2n * dot);
+                g[0] = h0 * rex + v0 * rdx; g[1] = h0 * rey + v0 * rdy; g[2] = h0 * rez + v0 * rdz;
+                g[3] = h1 * rex + v1 * rdx; g[4] = h1 * rey + v1 * rdy; g[5] = h1 * rez + v1 * rdz;
+                g[6] = h2 * rex + v2 * rdx; g[7] = h2 * rey + v2 * rdy; g[8] = h2 * rez + v2 * rdz;
+            }
+            g[9] = h0; g[10] = h1; g[11] = h2;
+            T = Tn;  // unchanged for lanes that did not hit
+            if (hit && (T < c.min_transmittance)) alive = false;
+
+            const float r = wave_transpose_reduce16(g, lane);
+            if ((lane & 12u) == 0u) atomicAdd(&acc[j * W + my_slot], r);  // 16 lanes, 16 distinct addresses
+            if (kDistGrad) {
+                const float t0 = wave_sum_lane63(gs0), t1 = wave_sum_lane63(gs1), t2 = wave_sum_lane63(gs2);
+                if (lane == 63) {
+                    atomicAdd(&acc[j * W + 16], t0);
+                    atomicAdd(&acc[j * W + 17], t1);
+                    atomicAdd(&acc[j * W + 18], t2);
                 }
             }
-            if (__ballot(hit) != 0ull) {  // wave-uniform: skip the reduction when no lane of this wave hit entry j
-                if (!hit) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) g[k] = 0.0f;
+        };
+        // software pipeline, unrolled by two so the prefetched parameters alternate between two register sets (no
+        // per-iteration register moves): entry j+1 is fetched from LDS while entry j is evaluated
+        {
+            float4 a0 = stage[0].mu_sigma, a1 = stage[0].m0, a2 = stage[0].m1, a3 = stage[0].m2;
+            float4 b0, b1, b2, b3;
+            uint32_t j = 0;
+            while (j < cnt) {
+                if (__ballot(alive) == 0ull) break;
+                {
+                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
+                    b0 = stage[jn].mu_sigma; b1 = stage[jn].m0; b2 = stage[jn].m1; b3 = stage[jn].m2;
                 }
-                const float r = wave_transpose_reduce16(g, lane);
-                atomicAdd(&acc[j * W + my_slot], r);  // one ds_add_f32 for the whole wave (4 rows share 16 addresses)
-                if (kDistGrad) {
-                    const float t0 = wave_sum_lane63(gs0), t1 = wave_sum_lane63(gs1), t2 = wave_sum_lane63(gs2);
-                    if (lane == 63) {
-                        atomicAdd(&acc[j * W + 16], t0);
-                        atomicAdd(&acc[j * W + 17], t1);
-                        atomicAdd(&acc[j * W + 18], t2);
-                    }
+                entry(a0, a1, a2, a3, j);
+                if (++j >= cnt) break;
+                if (__ballot(alive) == 0ull) break;
+                {
+                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
+                    a0 = stage[jn].mu_sigma; a1 = stage[jn].m0; a2 = stage[jn].m1; a3 = stage[jn].m2;
                 }
+                entry(b0, b1, b2, b3, j);
+                ++j;
             }
         }
 
