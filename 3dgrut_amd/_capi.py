@@ -58,6 +58,7 @@ class GutStats(C.Structure):
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
+           "gut_photometric_workspace_bytes", "gut_photometric_loss",
            "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
 
 _lib = None
@@ -95,6 +96,9 @@ def load():
     lib.gut_ssim_workspace_bytes.restype = C.c_size_t
     lib.gut_ssim_forward.argtypes = [vp, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp]
     lib.gut_ssim_backward.argtypes = [vp, i32, i32, i32, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.gut_photometric_workspace_bytes.argtypes = [i32, i32]
+    lib.gut_photometric_workspace_bytes.restype = C.c_size_t
+    lib.gut_photometric_loss.argtypes = [vp, i32, i32, vp, vp, C.c_float, C.c_float, C.c_float, vp, vp, vp]
     lib.gut_trace_bwd_ex.argtypes = [vp, vp, u32, i32, u32, f_p, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera),
                                      f_p, f_p, f_p, f_p, f_p, f_p, u32]
     lib.gut_activate_pack.argtypes = [vp, u32, vp, vp]

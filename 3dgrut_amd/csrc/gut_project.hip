@@ -485,8 +485,10 @@ __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, Rende
     // The 64 Gaussians of a wave own one contiguous 12 KiB block of the [N,48] SH tensor.  It is read with fully
     // coalesced 16-byte loads and transposed through a wave-private LDS region (32 rows x 49 dwords, two passes;
     // no workgroup barrier: LDS operations of one wave execute in order) so that each lane ends up with its own row.
+    // q / 12 never exceeds 63, so the mask shift is in range.
     const bool vis = cnt != 0;
-    if (__ballot(vis) != 0ull) {
+    const unsigned long long vis_mask = __ballot(vis);
+    if (vis_mask != 0ull) {
         float* wl = sh_lds + wave * 32 * kShRow;
         const float4* src = reinterpret_cast<const float4*>(sph48 + (size_t)wave_first * 48);
         float Y[16];
@@ -502,7 +504,9 @@ __global__ __launch_bounds__(kBlock) void k_project_on_tiles(ViewParams v, Rende
 #pragma unroll
         for (int it = 0; it < 12; ++it) {
             const uint32_t q = (uint32_t)it * 64u + (uint32_t)lane;  // float4 index inside the 12 KiB block
-            shq[it] = (q < rows_here * 12u) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // rows are 192 B = three whole 64-byte lines: rows of culled Gaussians are not fetched at all
+            const bool wanted = (q < rows_here * 12u) && ((vis_mask >> (q / 12u)) & 1ull);
+            shq[it] = wanted ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {

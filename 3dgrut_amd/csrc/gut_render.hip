@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                         // hitT = | s * grd * (grd . -gro) |
                         const float proj = -(u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (grd.-gro)/|u|
                         const float h0 = c0.w * u0 * proj, h1 = c1.w * u1 * proj, h2 = c2.w * u2 * proj;
-                        const float hit_t = sqrtf(h0 * h0 + h1 * h1 + h2 * h2);
+                        const float hit_t = fast_sqrt(h0 * h0 + h1 * h1 + h2 * h2);
                         if ((hit_t > ray.tmin) && (hit_t < ray.tmax)) {
                             const float w = alpha * T;
                             dsum += hit_t * w;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
                 const float proj = -(d0 * o0 + d1 * o1 + d2n * o2);
                 const float s0 = m0.w * d0 * proj, s1 = m1.w * d1 * proj, s2 = m2.w * d2n * proj;  // grds
                 const float gsq = s0 * s0 + s1 * s1 + s2 * s2;
-                const float gdist = sqrtf(gsq);
+                const float gdist = fast_sqrt(gsq);
                 ga_hit = gdist * T * gd;
                 if (gsq > 0.0f) {
                     const float kk = (w / gdist) * gd;

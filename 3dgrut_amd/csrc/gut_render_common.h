@@ -7,6 +7,7 @@ namespace gut {
 // ---- small helpers ------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, ~1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 struct RayState {

@@ -89,7 +89,7 @@ __device__ __forceinline__ bool eval_entry(const RenderConsts& c, const RayState
     if (!((resp > c.min_response) && (alpha > c.alpha_threshold))) return false;
     const float proj = -(u0 * o0 + u1 * o1 + u2 * o2) * il2;
     const float h0 = e.m0.w * u0 * proj, h1 = e.m1.w * u1 * proj, h2 = e.m2.w * u2 * proj;
-    hit_t = sqrtf(h0 * h0 + h1 * h1 + h2 * h2);
+    hit_t = fast_sqrt(h0 * h0 + h1 * h1 + h2 * h2);
     return (hit_t > ray.tmin) && (hit_t < ray.tmax);
 }
 

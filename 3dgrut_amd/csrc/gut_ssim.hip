@@ -28,16 +28,24 @@ __constant__ float c_gauss[kWin] = {0.001028380123898387f, 0.0075987582094967365
 struct ImgView {
     int H, W, C;
     long long sc, sh, sw;  // element strides: channel, row, pixel
+    // fused photometric loss only: img1 is the tracer's [H,W,4] rgba and the compared image is
+    // rgb + background * (1 - alpha) (BackgroundColor.forward, model/background.py:78-93); alpha_offset < 0 = plain image
+    long long alpha_offset;  // element offset of alpha relative to channel 0 of the same pixel
+    float background;        // constant background colour (0 black, 1 white)
 };
 
 __device__ __forceinline__ float load_px(const float* __restrict__ img, const ImgView& v, int c, int y, int x) {
     if (x < 0 || y < 0 || x >= v.W || y >= v.H) return 0.0f;
-    return img[(long long)c * v.sc + (long long)y * v.sh + (long long)x * v.sw];
+    const long long o = (long long)y * v.sh + (long long)x * v.sw;
+    float p = img[o + (long long)c * v.sc];
+    if (v.alpha_offset >= 0 && v.background != 0.0f) p += v.background * (1.0f - img[o + v.alpha_offset]);
+    return p;
 }
 
 // forward: partial sums of the valid-region SSIM map per workgroup + derivative maps (planar [C,H,W])
-__global__ __launch_bounds__(256) void k_ssim_fwd(ImgView v, const float* __restrict__ img1, const float* __restrict__ img2,
-                                                 float* __restrict__ partial, float* __restrict__ dm_dmu1,
+__global__ __launch_bounds__(256) void k_ssim_fwd(ImgView v, ImgView v2, const float* __restrict__ img1,
+                                                 const float* __restrict__ img2, float* __restrict__ partial,
+                                                 float* __restrict__ partial_l1, float* __restrict__ dm_dmu1,
                                                  float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12) {
     __shared__ float s1[kPatch][kPatch + 1], s2[kPatch][kPatch + 1];
     __shared__ float h[5][kPatch][kSTile + 1];  // horizontally filtered: mu1, mu2, x^2, y^2, xy
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(ImgView v, const float* __rest
     for (int i = tid; i < kPatch * kPatch; i += 256) {
         const int py = i / kPatch, pxx = i - py * kPatch;
         s1[py][pxx] = load_px(img1, v, c, y0 + py - kHalo, x0 + pxx - kHalo);
-        s2[py][pxx] = load_px(img2, v, c, y0 + py - kHalo, x0 + pxx - kHalo);
+        s2[py][pxx] = load_px(img2, v2, c, y0 + py - kHalo, x0 + pxx - kHalo);
     }
     __syncthreads();
     for (int i = tid; i < kPatch * kSTile; i += 256) {
@@ -72,8 +80,9 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(ImgView v, const float* __rest
         e11 += w * h[2][oy + k][ox]; e22 += w * h[3][oy + k][ox]; e12 += w * h[4][oy + k][ox];
     }
     const int x = x0 + ox, y = y0 + oy;
-    float val = 0.0f;
+    float val = 0.0f, l1 = 0.0f;
     if (x < v.W && y < v.H) {
+        l1 = fabsf(s1[oy + kHalo][ox + kHalo] - s2[oy + kHalo][ox + kHalo]);
         const float C1 = 0.0001f, C2 = 0.0009f;
         const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
         const float sg1 = e11 - mu1_sq, sg2 = e22 - mu2_sq, sg12 = e12 - mu12;
@@ -90,7 +99,15 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(ImgView v, const float* __rest
     for (int mk = 32; mk >= 1; mk >>= 1) val += __shfl_xor(val, mk);
     if ((tid & 63) == 0) red[tid >> 6] = val;
     __syncthreads();
-    if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    const int slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0) partial[slot] = red[0] + red[1] + red[2] + red[3];
+    if (partial_l1) {  // block-uniform
+        __syncthreads();
+        for (int mk = 32; mk >= 1; mk >>= 1) l1 += __shfl_xor(l1, mk);
+        if ((tid & 63) == 0) red[tid >> 6] = l1;
+        __syncthreads();
+        if (tid == 0) partial_l1[slot] = red[0] + red[1] + red[2] + red[3];
+    }
 }
 
 // deterministic final sum of the per-workgroup partials -> mean SSIM
@@ -105,17 +122,49 @@ __global__ __launch_bounds__(256) void k_ssim_finish(const float* __restrict__ p
     if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)inv_count);
 }
 
+// fused photometric loss: out3 = { lambda_l1 * L1 + lambda_ssim * (1 - SSIM), L1, SSIM }
+__global__ __launch_bounds__(256) void k_photometric_finish(const float* __restrict__ partial, const float* __restrict__ partial_l1,
+                                                           int n, float inv_count_ssim, float inv_count_l1, float lambda_l1,
+                                                           float lambda_ssim, float* __restrict__ out3) {
+    __shared__ double red[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        a += (double)partial[i];
+        b += (double)partial_l1[i];
+    }
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+        a += __shfl_xor(a, mk);
+        b += __shfl_xor(b, mk);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ssim = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) * (double)inv_count_ssim);
+        const float l1 = (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) * (double)inv_count_l1);
+        out3[0] = lambda_l1 * l1 + lambda_ssim * (1.0f - ssim);
+        out3[1] = l1;
+        out3[2] = ssim;
+    }
+}
+
 // backward: d(mean ssim)/d(img1) * upstream, written through the same strides as img1
-__global__ __launch_bounds__(256) void k_ssim_bwd(ImgView v, const float* __restrict__ img1, const float* __restrict__ img2,
-                                                 const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dsigma1_sq,
-                                                 const float* __restrict__ dm_dsigma12, const float* __restrict__ upstream,
-                                                 float inv_count, float* __restrict__ grad) {
+// fused photometric loss (upstream == nullptr): grad = -lambda_ssim * d(mean ssim) + lambda_l1 * sign(p - q) / numel, and
+// channel 0's workgroups also write the alpha gradient slot (-background * sum of the colour gradients is added by
+// k_alpha_grad for a non-black background; zero for black).
+__global__ __launch_bounds__(256) void k_ssim_bwd(ImgView v, ImgView v2, const float* __restrict__ img1,
+                                                 const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
+                                                 const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
+                                                 const float* __restrict__ upstream, float inv_count, float ssim_weight,
+                                                 float l1_weight, float* __restrict__ grad) {
     __shared__ float s[3][kPatch][kPatch + 1];
     __shared__ float h[3][kPatch][kSTile + 1];
     const int c = blockIdx.z;
     const int x0 = blockIdx.x * kSTile, y0 = blockIdx.y * kSTile;
     const int tid = threadIdx.x;
-    const float scale = upstream[0] * inv_count;
+    const float scale = (upstream ? upstream[0] : ssim_weight) * inv_count;
     for (int i = tid; i < kPatch * kPatch; i += 256) {
         const int py = i / kPatch, pxx = i - py * kPatch;
         const int x = x0 + pxx - kHalo, y = y0 + py - kHalo;
@@ -148,8 +197,22 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(ImgView v, const float* __rest
     const int x = x0 + ox, y = y0 + oy;
     if (x < v.W && y < v.H) {
         const long long o = (long long)c * v.sc + (long long)y * v.sh + (long long)x * v.sw;
-        const float p = img1[o], q = img2[o];
-        grad[o] = scale * (a + 2.0f * p * b + q * d);
+        const float p = load_px(img1, v, c, y, x), q = load_px(img2, v2, c, y, x);
+        float g = scale * (a + 2.0f * p * b + q * d);
+        if (l1_weight != 0.0f) g += l1_weight * (float)((p > q) - (p < q));
+        grad[o] = g;
+        if (v.alpha_offset >= 0 && c == 0) grad[o + v.alpha_offset] = 0.0f;
+    }
+}
+
+// d(loss)/d(alpha) = -background * (g_r + g_g + g_b) for rgb_out = rgb + background * (1 - alpha)
+__global__ __launch_bounds__(256) void k_alpha_grad(int pixels, float background, float* __restrict__ rgba_grad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < pixels) {
+        float4* g = reinterpret_cast<float4*>(rgba_grad) + i;
+        float4 t = *g;
+        t.w = -background * (t.x + t.y + t.z);
+        *g = t;
     }
 }
 
@@ -166,6 +229,8 @@ size_t gut_ssim_workspace_bytes(int32_t channels, int32_t height, int32_t width)
 static gut::ImgView make_view(int32_t C, int32_t H, int32_t W, int64_t sc, int64_t sh, int64_t sw) {
     gut::ImgView v;
     v.C = C; v.H = H; v.W = W; v.sc = sc; v.sh = sh; v.sw = sw;
+    v.alpha_offset = -1;
+    v.background = 0.0f;
     return v;
 }
 
@@ -179,7 +244,8 @@ int gut_ssim_forward(void* stream, int32_t channels, int32_t height, int32_t wid
     float* partial = maps + 3 * plane;
     const dim3 grid((width + 15) / 16, (height + 15) / 16, channels);
     const gut::ImgView v = make_view(channels, height, width, stride_c, stride_h, stride_w);
-    hipLaunchKernelGGL(gut::k_ssim_fwd, grid, dim3(256), 0, s, v, d_img1, d_img2, partial, maps, maps + plane, maps + 2 * plane);
+    hipLaunchKernelGGL(gut::k_ssim_fwd, grid, dim3(256), 0, s, v, v, d_img1, d_img2, partial, (float*)nullptr, maps, maps + plane,
+                       maps + 2 * plane);
     const double count = (double)channels * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
     hipLaunchKernelGGL(gut::k_ssim_finish, dim3(1), dim3(256), 0, s, partial, (int)(grid.x * grid.y * grid.z), (float)(1.0 / count),
                        d_mean_ssim);
@@ -196,8 +262,43 @@ int gut_ssim_backward(void* stream, int32_t channels, int32_t height, int32_t wi
     const dim3 grid((width + 15) / 16, (height + 15) / 16, channels);
     const gut::ImgView v = make_view(channels, height, width, stride_c, stride_h, stride_w);
     const double count = (double)channels * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
-    hipLaunchKernelGGL(gut::k_ssim_bwd, grid, dim3(256), 0, s, v, d_img1, d_img2, maps, maps + plane, maps + 2 * plane, d_upstream,
-                       (float)(1.0 / count), d_grad_img1);
+    hipLaunchKernelGGL(gut::k_ssim_bwd, grid, dim3(256), 0, s, v, v, d_img1, d_img2, maps, maps + plane, maps + 2 * plane, d_upstream,
+                       (float)(1.0 / count), 0.0f, 0.0f, d_grad_img1);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+size_t gut_photometric_workspace_bytes(int32_t height, int32_t width) {
+    const size_t tiles = (size_t)((width + 15) / 16) * ((height + 15) / 16) * 3 * sizeof(float);
+    return gut_ssim_workspace_bytes(3, height, width) + tiles;
+}
+
+int gut_photometric_loss(void* stream, int32_t height, int32_t width, const float* d_rgba, const float* d_gt_rgb, float background,
+                         float lambda_l1, float lambda_ssim, void* d_workspace, float* d_loss3, float* d_rgba_grad) {
+    if (!d_rgba || !d_gt_rgb || !d_workspace || !d_loss3 || !d_rgba_grad) return 1;
+    if (height <= 2 * gut::kHalo || width <= 2 * gut::kHalo) return 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t plane = (size_t)3 * height * width;
+    float* maps = static_cast<float*>(d_workspace);
+    float* partial = maps + 3 * plane;
+    const dim3 grid((width + 15) / 16, (height + 15) / 16, 3);
+    const int nblocks = (int)(grid.x * grid.y * grid.z);
+    float* partial_l1 = partial + nblocks + 64;
+    gut::ImgView v = make_view(3, height, width, 1, 4 * (int64_t)width, 4);   // rgba, interleaved
+    v.alpha_offset = 3;
+    v.background = background;
+    const gut::ImgView g = make_view(3, height, width, 1, 3 * (int64_t)width, 3);  // ground truth, interleaved rgb
+    hipLaunchKernelGGL(gut::k_ssim_fwd, grid, dim3(256), 0, s, v, g, d_rgba, d_gt_rgb, partial, partial_l1, maps, maps + plane,
+                       maps + 2 * plane);
+    const double count = 3.0 * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
+    const double numel = 3.0 * height * width;
+    hipLaunchKernelGGL(gut::k_photometric_finish, dim3(1), dim3(256), 0, s, partial, partial_l1, nblocks, (float)(1.0 / count),
+                       (float)(1.0 / numel), lambda_l1, lambda_ssim, d_loss3);
+    hipLaunchKernelGGL(gut::k_ssim_bwd, grid, dim3(256), 0, s, v, g, d_rgba, d_gt_rgb, maps, maps + plane, maps + 2 * plane,
+                       (const float*)nullptr, (float)(1.0 / count), -lambda_ssim, (float)(lambda_l1 / numel), d_rgba_grad);
+    if (background != 0.0f) {
+        const int pixels = height * width;
+        hipLaunchKernelGGL(gut::k_alpha_grad, dim3((pixels + 255) / 256), dim3(256), 0, s, pixels, background, d_rgba_grad);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

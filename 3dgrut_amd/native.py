@@ -77,7 +77,7 @@ class NativeGaussianModel:
 
 class NativeTrainStep:
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
-                 betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0):
+                 betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2):
         self.model = model
         self.tracer = tracer
         self.raster: SplatRaster = tracer.tracer_wrapper
@@ -98,11 +98,19 @@ class NativeTrainStep:
         z = lambda c: torch.zeros((n, c), dtype=torch.float32, device=dev)
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
         self.fused = bool(fused_sh_adam)
+        self.fused_loss = bool(fused_loss)
+        self.lambda_l1, self.lambda_ssim = float(lambda_l1), float(lambda_ssim)
+        self._loss_ws = None
+        self._loss3 = None
+        self._cam_ring = None
+        self._cam_dev = None
         self.rank = int(rank)
         self.force_exchange = os.environ.get("GUT_DP_FORCE_COLLECTIVES") == "1"  # see dp._skip
         self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
         self.resize_workspace()
         self.step_id = 0
+        self.phase_timing = False   # record HIP events around the phases of step() (bench / profiling)
+        self._phase_events = []
 
     def resize_workspace(self):
         """(Re)allocate the per-step buffers for the current number of Gaussians (called after densification)."""
@@ -148,25 +156,89 @@ class NativeTrainStep:
         self._ctx = (batch, sensor, poses, rgba, dist_)
         return rgba, dist_, hits, vis
 
+    def _sensor_position(self, batch):
+        """Sensor position [3] on the device.  A host-resident batch.T_to_world (an extension of the Batch contract: the
+        reference keeps it on the GPU and reads it back every step, tracer.py:353-356) goes through a small ring of
+        pinned staging buffers so that no step ever blocks on the GPU."""
+        t = batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32)
+        if t.is_cuda:
+            return t.contiguous()
+        if self._cam_ring is None:
+            self._cam_ring = [torch.empty(3, dtype=torch.float32).pin_memory() for _ in range(8)]
+            self._cam_dev = [torch.empty(3, dtype=torch.float32, device=self.model.raw.device) for _ in range(8)]
+        k = self.step_id % len(self._cam_ring)
+        self._cam_ring[k].copy_(t)
+        self._cam_dev[k].copy_(self._cam_ring[k], non_blocking=True)
+        return self._cam_dev[k]
+
+    def _mark(self, evs):
+        if evs is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+
+    def phase_times_mean(self, reset=True):
+        """Mean milliseconds per phase over the steps recorded since the last call (phase_timing must be on):
+        forward (activate + trace), loss (image-sized autograd fwd+bwd), backward (trace_bwd), update (exchange + Adam)."""
+        names = ("forward", "loss", "backward", "update")
+        if not self._phase_events:
+            return {}
+        torch.cuda.synchronize(self.model.raw.device)
+        acc = [0.0] * len(names)
+        for evs in self._phase_events:
+            for k in range(len(names)):
+                acc[k] += evs[k].elapsed_time(evs[k + 1])
+        n = len(self._phase_events)
+        if reset:
+            self._phase_events = []
+        return {names[k]: acc[k] / n for k in range(len(names))}
+
     def step(self, batch):
         m = self.model
+        evs = [] if self.phase_timing else None
+        self._mark(evs)
         rgba, dist_, hits, vis = self.forward(batch)
-        rgba_leaf = rgba.detach().requires_grad_(True)
-        pred_rgb = rgba_leaf[..., :3].unsqueeze(0)
-        pred_opacity = rgba_leaf[..., 3:].unsqueeze(0)
-        pred_rgb, pred_opacity = m.background(batch.T_to_world, batch.rays_dir, pred_rgb, pred_opacity, True)
-        loss = photometric_loss(pred_rgb, batch.rgb_gt)
-        loss.backward()  # image-sized autograd only
+        self._mark(evs)
+        gt = batch.rgb_gt
+        if self.fused_loss and m.background_color in ("black", "white") and gt.dtype == torch.float32 and gt.is_contiguous() \
+                and gt.numel() == rgba.shape[0] * rgba.shape[1] * 3:
+            # loss value and d(loss)/d(rgba) in three HIP launches (csrc/gut_ssim.hip: gut_photometric_loss)
+            H, W = rgba.shape[0], rgba.shape[1]
+            need = self._lib.gut_photometric_workspace_bytes(H, W)
+            if self._loss_ws is None or self._loss_ws.numel() * 4 < need:
+                self._loss_ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=rgba.device)
+                self._loss3 = torch.empty((3,), dtype=torch.float32, device=rgba.device)
+            rgba_grad = torch.empty_like(rgba)
+            st = torch.cuda.current_stream(rgba.device).cuda_stream
+            rc = self._lib.gut_photometric_loss(C.c_void_p(st), H, W, rgba.data_ptr(), gt.data_ptr(),
+                                                1.0 if m.background_color == "white" else 0.0, self.lambda_l1, self.lambda_ssim,
+                                                self._loss_ws.data_ptr(), self._loss3.data_ptr(), rgba_grad.data_ptr())
+            if rc:
+                raise RuntimeError(f"[3dgut] photometric_loss failed ({rc})")
+            loss = self._loss3[0].clone()
+            pred_rgb = rgba[..., :3].unsqueeze(0)
+            if m.background_color == "white":
+                pred_rgb = pred_rgb + (1.0 - rgba[..., 3:].unsqueeze(0))
+        else:
+            rgba_leaf = rgba.detach().requires_grad_(True)
+            pred_rgb = rgba_leaf[..., :3].unsqueeze(0)
+            pred_opacity = rgba_leaf[..., 3:].unsqueeze(0)
+            pred_rgb, pred_opacity = m.background(batch.T_to_world, batch.rays_dir, pred_rgb, pred_opacity, True)
+            loss = photometric_loss(pred_rgb, gt, self.lambda_l1, self.lambda_ssim)
+            loss.backward()  # image-sized autograd only
+            rgba_grad = rgba_leaf.grad
+        self._mark(evs)
         _, sensor, poses, _, _ = self._ctx
         bwd_args = (self.step_id, m.n_active_features, self.act, m.features, batch.rays_ori.contiguous(),
                     batch.rays_dir.contiguous(), None, sensor, poses.timestamps_us[0], poses.timestamps_us[1],
-                    poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_leaf.grad, dist_, None)
+                    poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_grad, dist_, None)
         vmask = None
         if self.fused:
             w = max(1, self.world_size)
             self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, compact_radiance_grads=True,
                                   out=(self.g12, self.mrgb[self.rank if w > 1 else 0]))
-            cam_local = batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32).contiguous()
+            self._mark(evs)
+            cam_local = self._sensor_position(batch)
             if self.post_backward_hook is not None:  # per-view statistics, before the exchange (strategy/gs.py:106-115)
                 self.post_backward_hook(self.g12[:, 0:3], cam_local)
             if w > 1 or self.force_exchange:
@@ -192,6 +264,7 @@ class NativeTrainStep:
                 raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
         else:
             self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, out=(self.g12, self.g48))
+            self._mark(evs)
             if self.post_backward_hook is not None:
                 self.post_backward_hook(self.g12[:, 0:3], batch.T_to_world.reshape(4, 4)[:3, 3].to(torch.float32))
             if self.world_size > 1 or self.force_exchange:
@@ -201,6 +274,9 @@ class NativeTrainStep:
             vmask = vis.reshape(-1) if self.selective else None
             self._adam(m.raw, self.g12, self.m12, self.v12, self.lr12, vmask)
             self._adam(m.features, self.g48, self.m48, self.v48, self.lr48, vmask)
+        self._mark(evs)
+        if evs is not None:
+            self._phase_events.append(evs)
         self.step_id += 1
         return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
 

@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: initialise RCCL with world size 1 and issue the data-parallel collectives anyway "
                          "(exercises the N>1 call sequence on a one-GPU box; the number is NOT a bench line)")
+    ap.add_argument("--device-pose", dest="host_pose", action="store_false",
+                    help="hand the 4x4 camera pose over as a GPU tensor (reference layout; costs one blocking read-back per step)")
     ap.add_argument("--selective-adam", action="store_true", help="visibility-masked Adam (reference SelectiveAdam)")
     args = ap.parse_args()
 
@@ -179,7 +181,10 @@ def main():
 
     def batch_for(step):
         v = dp_mod.view_index(step, rank, world, n_views)
-        return gut.Batch(rays_ori=ro_t, rays_dir=rd_t, T_to_world=torch.as_tensor(c2ws[v], device=dev)[None], rgb_gt=gt,
+        # the 4x4 pose stays on the host (the tracer needs it there to fill the camera struct; a device tensor would
+        # cost a blocking read-back per step, as in the reference's tracer.py:353-356)
+        pose = torch.as_tensor(c2ws[v])[None] if args.host_pose else torch.as_tensor(c2ws[v], device=dev)[None]
+        return gut.Batch(rays_ori=ro_t, rays_dir=rd_t, T_to_world=pose, rgb_gt=gt,
                          intrinsics_OpenCVPinholeCameraModelParameters=K)
 
     def barrier():
@@ -193,6 +198,8 @@ def main():
     barrier()
     raster.kernel_times_mean()  # reset the per-kernel event ring
     raster.collect_times()
+    if hasattr(stepper, "phase_timing"):
+        stepper.phase_timing = True
     t0 = time.perf_counter()
     for s in range(args.steps):
         stepper.step(batch_for(args.warmup + s))
@@ -203,6 +210,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    phases = stepper.phase_times_mean() if hasattr(stepper, "phase_times_mean") else {}
+    if hasattr(stepper, "phase_timing"):
+        stepper.phase_timing = False
     ktimes, kcount = raster.kernel_times_mean()
     fb = raster.collect_times()
     stats = raster.stats()
@@ -245,7 +255,7 @@ def main():
                        "trainer": args.trainer},
             "render_ms_per_frame": render_ms,
             "forward_render_ms_in_train": fb.get("forward_render"), "backward_render_ms_in_train": fb.get("backward_render"),
-            "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
+            "phase_ms": phases, "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
             "reference_rtx5090": {"images_per_s": 31.6, "render_ms": 3.64, "note": "README.md:320, different hardware, real dataset"},
         }
         if world == 1 and not args.no_cpu_baseline:

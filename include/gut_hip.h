@@ -193,6 +193,15 @@ int gut_ssim_backward(void* stream, int32_t channels, int32_t height, int32_t wi
                       int64_t stride_w, const float* d_img1, const float* d_img2, const void* d_workspace,
                       const float* d_upstream, float* d_grad_img1);
 
+/* Fused photometric loss of the reference's train step (trainer.py:425-449, configs/base_gs.yaml:111-119), forward AND
+ * gradient in three launches, no autograd:  image = rgb + background * (1 - alpha)  (model/background.py:78-93,
+ * background 0 = black, 1 = white);  loss = lambda_l1 * mean|image - gt| + lambda_ssim * (1 - SSIM(image, gt)).
+ * d_rgba [H,W,4] is gut_trace's ray_radiance_density, d_gt_rgb [H,W,3]; d_loss3 receives {loss, L1, SSIM};
+ * d_rgba_grad [H,W,4] receives d(loss)/d(rgba), ready to be passed to gut_trace_bwd. */
+size_t gut_photometric_workspace_bytes(int32_t height, int32_t width);
+int gut_photometric_loss(void* stream, int32_t height, int32_t width, const float* d_rgba, const float* d_gt_rgb, float background,
+                         float lambda_l1, float lambda_ssim, void* d_workspace, float* d_loss3, float* d_rgba_grad);
+
 /* ---- "next" row N2: parameter activation + fused Adam ----
  * gut_activate_pack: raw rows [N,12] (pos3, density logit, quat4, log-scale3, unused) -> activated rows
  *   (pos3, sigmoid, quat/|quat|, exp, |quat|) = the particle_density the tracer consumes (model.py:74-93 +

@@ -45,3 +45,37 @@ def test_photometric_loss_value():
     assert abs(float(loss) - float(ref)) <= 5e-6
     loss.backward()
     assert torch.isfinite(pred.grad).all()
+
+
+@pytest.mark.parametrize("background", ["black", "white"])
+@pytest.mark.parametrize("hw", [(40, 56), (37, 53), (822, 1237)])
+def test_fused_photometric_loss_and_gradient(background, hw):
+    """gut_photometric_loss (loss + d/d(rgba) without autograd) vs fp64 torch autograd of
+    0.8*L1 + 0.2*(1-SSIM) on rgb + background*(1-alpha).  Tolerance: |loss diff| <= 5e-6, gradient rel-L2 <= 1e-4."""
+    import ctypes as C
+    capi = importlib.import_module("3dgrut_amd._capi")
+    lib = capi.load()
+    H, W = hw
+    g = torch.Generator().manual_seed(3)
+    rgba = torch.rand((H, W, 4), generator=g)
+    gt = torch.rand((H, W, 3), generator=g)
+    bg = 1.0 if background == "white" else 0.0
+    x = rgba.cuda().contiguous(); y = gt.cuda().contiguous()
+    ws = torch.empty(((lib.gut_photometric_workspace_bytes(H, W) + 3) // 4,), dtype=torch.float32, device="cuda")
+    out3 = torch.empty(3, dtype=torch.float32, device="cuda")
+    grad = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.gut_photometric_loss(C.c_void_p(st), H, W, x.data_ptr(), y.data_ptr(), bg, 0.8, 0.2, ws.data_ptr(), out3.data_ptr(),
+                                  grad.data_ptr())
+    assert rc == 0
+    r64 = rgba.double().requires_grad_(True)
+    img = r64[..., :3] + bg * (1.0 - r64[..., 3:])
+    ref = train.photometric_loss_torch(img.unsqueeze(0), gt.double().unsqueeze(0), window=train._gauss_window(dtype=torch.float64))
+    ref.backward()
+    o = out3.cpu().double()
+    assert abs(float(o[0]) - float(ref)) <= 5e-6
+    assert abs(float(o[1]) - float((img - gt.double()).abs().mean())) <= 2e-6
+    got = grad.cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - r64.grad).norm() / r64.grad.norm())
+    assert err <= 1e-4, err
