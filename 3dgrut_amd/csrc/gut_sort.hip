@@ -21,11 +21,13 @@ hipError_t run_scan(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t
     return rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), s);
 }
 
-// rocPRIM's tuned gfx950 entry for (8-byte key, 4-byte value) is 512 threads x 16 items, 8-bit digits; on the
-// bench's 9.4 M (tile|depth) pairs 512 x 12 measured 6 % faster (tools/sort_sweep.hip: 0.574 vs 0.612 ms).
+// rocPRIM's tuned gfx950 entry for (8-byte key, 4-byte value) is 512 threads x 16 items with 8-bit digits: 6 passes over
+// the 44 key bits of a 4056-tile frame.  9-bit digits cover them in 5 passes; with 1024 x 8 sort blocks and a 512 x 32
+// histogram the bench's 9.4 M (tile|depth) pairs sort in 0.446 ms instead of 0.612 ms (tools/sort_sweep.hip; 10-bit
+// digits lose again to LDS pressure, 11-bit digits do not fit).
 using SortConfig = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<512, 12>, 8,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 32>, rocprim::kernel_config<1024, 8>, 9,
                                         rocprim::block_radix_rank_algorithm::match>>;
 
 size_t sort_temp_bytes(uint32_t m, int end_bit) {

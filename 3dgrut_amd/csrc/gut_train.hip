@@ -12,17 +12,18 @@ namespace gut {
 // raw row: pos3 | density logit | quat4 (unnormalised) | log-scale3 | unused
 // act row: pos3 | sigmoid       | quat4 / |quat|       | exp3       | |quat|   (the norm rides in the pad column so
 //          that the backward epilogue can chain through the normalisation without re-reading the raw row)
+__device__ __forceinline__ void activate_row(const float4& a, const float4& q, const float4& s, float4* __restrict__ act_row) {
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);  // torch.nn.functional.normalize eps
+    act_row[0] = make_float4(a.x, a.y, a.z, 1.0f / (1.0f + expf(-a.w)));
+    act_row[1] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    act_row[2] = make_float4(expf(s.x), expf(s.y), expf(s.z), fmaxf(nrm, 1e-12f));
+}
+
 __global__ __launch_bounds__(kBlock) void k_activate_pack(uint32_t n, const float4* __restrict__ raw, float4* __restrict__ act) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const float4 a = raw[3 * (size_t)i + 0];
-    const float4 q = raw[3 * (size_t)i + 1];
-    const float4 s = raw[3 * (size_t)i + 2];
-    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    const float inv = 1.0f / fmaxf(nrm, 1e-12f);  // torch.nn.functional.normalize eps
-    act[3 * (size_t)i + 0] = make_float4(a.x, a.y, a.z, 1.0f / (1.0f + expf(-a.w)));
-    act[3 * (size_t)i + 1] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-    act[3 * (size_t)i + 2] = make_float4(expf(s.x), expf(s.y), expf(s.z), fmaxf(nrm, 1e-12f));
+    activate_row(raw[3 * (size_t)i + 0], raw[3 * (size_t)i + 1], raw[3 * (size_t)i + 2], act + 3 * (size_t)i);
 }
 
 struct AdamParams {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
                                                    const float4* __restrict__ grad12, float4* __restrict__ p12,
                                                    float4* __restrict__ m12, float4* __restrict__ v12, float4* __restrict__ p48,
                                                    float4* __restrict__ m48, float4* __restrict__ v48,
-                                                   const float* __restrict__ visibility) {
+                                                   const float* __restrict__ visibility, float4* __restrict__ act12) {
     constexpr int kRow = 49;
     __shared__ float tile[(kBlock / 64) * 64 * kRow];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -168,6 +169,9 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
             p12[3 * (size_t)i + 0] = a; p12[3 * (size_t)i + 1] = b; p12[3 * (size_t)i + 2] = c;
             m12[3 * (size_t)i + 0] = ma; m12[3 * (size_t)i + 1] = mb; m12[3 * (size_t)i + 2] = mc;
             v12[3 * (size_t)i + 0] = va; v12[3 * (size_t)i + 1] = vb; v12[3 * (size_t)i + 2] = vc;
+            // the next forward's activated row, while the updated raw row is still in registers (saves k_activate_pack's
+            // separate pass over [N,12]); rows SelectiveAdam leaves untouched keep their previous activation
+            if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
             // --- rebuild the SH gradient of this Gaussian from the compact per-view rows ---
             for (uint32_t vw = 0; vw < sp.views; ++vw) {
                 const float* mr = mrgb + ((size_t)vw * sp.n + i) * 3;
@@ -273,7 +277,7 @@ static void fill_adam(gut::AdamParams& ap, const float* lr, uint32_t cols, float
 int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* d_camera_positions,
                      const float* d_mrgb, const float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
                      float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
-                     float beta1, float beta2, float eps, uint32_t step, const float* d_visibility) {
+                     float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out) {
     if (num_particles == 0) return 0;
     if (!d_camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
         !lr12 || !lr48)
@@ -288,7 +292,7 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
                        static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<const float4*>(d_raw_grad12),
                        reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v),
                        reinterpret_cast<float4*>(d_sh48), reinterpret_cast<float4*>(d_sh_m), reinterpret_cast<float4*>(d_sh_v),
-                       d_visibility);
+                       d_visibility, reinterpret_cast<float4*>(d_act12_out));
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

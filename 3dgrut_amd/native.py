@@ -104,6 +104,7 @@ class NativeTrainStep:
         self._loss3 = None
         self._cam_ring = None
         self._cam_dev = None
+        self._act_key = None
         self.rank = int(rank)
         self.force_exchange = os.environ.get("GUT_DP_FORCE_COLLECTIVES") == "1"  # see dp._skip
         self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
@@ -116,6 +117,7 @@ class NativeTrainStep:
         """(Re)allocate the per-step buffers for the current number of Gaussians (called after densification)."""
         n = self.model.num_gaussians
         dev = self.model.raw.device
+        self._act_key = None
         self.act = torch.empty((n, 12), dtype=torch.float32, device=dev)
         self.g12 = torch.empty((n, 12), dtype=torch.float32, device=dev)
         if self.fused:
@@ -129,6 +131,9 @@ class NativeTrainStep:
 
     # ---- pieces ----
     def activate(self):
+        raw = self.model.raw
+        if self._act_key == (raw.data_ptr(), raw._version, raw.shape[0]):
+            return self.act  # written by the previous step's fused Adam kernel; raw untouched since
         st = torch.cuda.current_stream(self.model.raw.device).cuda_stream
         rc = self._lib.gut_activate_pack(C.c_void_p(st), self.model.num_gaussians, self.model.raw.data_ptr(), self.act.data_ptr())
         if rc:
@@ -259,9 +264,11 @@ class NativeTrainStep:
                 self.g12.data_ptr(), 1.0 / w, m.raw.data_ptr(), self.m12.data_ptr(), self.v12.data_ptr(), m.features.data_ptr(),
                 self.m48.data_ptr(), self.v48.data_ptr(), self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p),
                 self.betas[0], self.betas[1], self.eps, 0 if self.selective else self.step_id + 1,
-                None if vmask is None else vmask.data_ptr())
+                None if vmask is None else vmask.data_ptr(), self.act.data_ptr())
             if rc:
                 raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
+            # any in-place torch edit of raw (densification, MCMC noise, ...) bumps _version and forces a fresh activation
+            self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
         else:
             self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, out=(self.g12, self.g48))
             self._mark(evs)

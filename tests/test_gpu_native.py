@@ -85,6 +85,36 @@ def test_native_step_matches_autograd_step(steps, fused):
     assert rel_l2(mn.features.cpu().numpy(), feats) <= tol
 
 
+def test_cached_activation_is_dropped_when_raw_parameters_are_edited():
+    """The fused Adam kernel leaves the next step's activated rows behind; an in-place edit of the raw parameters
+    (densification, MCMC noise) must force a fresh activation, and a host-resident pose must give the same step."""
+    sc = scenes.scene_c1(500, 4)
+    view = make_view("pinhole", 64, 64, cams.look_at_c2w((0.0, 0.1, -3.5), (0, 0, 0)), fx=60)
+    batch = to_batch(view, DEV)
+    batch.rgb_gt = torch.rand((1, 64, 64, 3), generator=torch.Generator().manual_seed(8)).to(DEV)
+    host_batch = to_batch(view, DEV)
+    host_batch.rgb_gt = batch.rgb_gt
+    host_batch.T_to_world = batch.T_to_world.cpu()
+    runs = []
+    for edit, b in ((False, batch), (True, batch), (True, host_batch)):
+        mn = native.NativeGaussianModel(sc, device=DEV)
+        tn = native.NativeTrainStep(mn, gut.Tracer({"render": {}}), scene_extent=1.0)
+        tn.step(b)
+        assert tn._act_key is not None
+        if edit:
+            mn.raw[:, 0:3].add_(0.05)      # in place: bumps the version counter
+        act = tn.activate().clone()
+        fresh = torch.empty_like(act)
+        native._capi.load().gut_activate_pack(None, mn.num_gaussians, mn.raw.data_ptr(), fresh.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(act, fresh)
+        loss, _ = tn.step(b)
+        runs.append((float(loss), mn.raw.clone()))
+    # device pose == host pose (parameters agree up to the summation order of the float atomics)
+    assert runs[1][0] == runs[2][0] and torch.allclose(runs[1][1], runs[2][1], rtol=1e-4, atol=1e-6)
+    assert runs[0][0] != runs[1][0]
+
+
 def test_mcmc_relocation_kernel_matches_formula():
     """gut_mcmc_relocation vs the closed form of strategy/src/gaussian_mcmc.cu:33-73 evaluated in float64."""
     import math

@@ -8,6 +8,7 @@
 
 template <class Config>
 float run(const char* name, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, size_t m, unsigned end_bit) {
+    if (getenv("ONLY") && !strstr(name, getenv("ONLY"))) return 0.f;
     size_t bytes = 0;
     rocprim::radix_sort_pairs<Config>(nullptr, bytes, kin, kout, vin, vout, m, 0u, end_bit, (hipStream_t)0);
     void* tmp; hipMalloc(&tmp, bytes);
@@ -42,32 +43,13 @@ int main() {
     hipMalloc(&kin, m * 8); hipMalloc(&kout, m * 8); hipMalloc(&vin, m * 4); hipMalloc(&vout, m * 4);
     hipMemcpy(kin, k.data(), m * 8, hipMemcpyHostToDevice); hipMemcpy(vin, v.data(), m * 4, hipMemcpyHostToDevice);
     using R = rocprim::block_radix_rank_algorithm;
-    run<rocprim::default_config>("default", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 512, 16, 8, R::match>>("512x16 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 1024, 8, 8, R::match>>("1024x8 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 256, 16, 8, R::match>>("256x16 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 256, 24, 8, R::match>>("256x24 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 512, 12, 8, R::match>>("512x12 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 512, 22, 8, R::match>>("512x22 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 512, 8, 8, R::match>>("512x8 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 1024, 12, 8, R::match>>("1024x12 8b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 512, 16, 7, R::match>>("512x16 7b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 512, 16, 6, R::match>>("512x16 6b match", kin, kout, vin, vout, m, end_bit);
-    run<cfg<512, 16, 512, 16, 5, R::match>>("512x16 5b match (9 passes)", kin, kout, vin, vout, m, end_bit);
-    // depth-only and tile-only sorts, to price the two-stage alternative
-    run<rocprim::default_config>("default, 13 bits @32", kin, kout, vin, vout, m, 13);
-    {
-        size_t n = 6000000, bytes = 0;
-        uint32_t *a = (uint32_t*)kin, *b = (uint32_t*)kout;
-        rocprim::radix_sort_pairs(nullptr, bytes, a, b, vin, vout, n, 0u, 32u, (hipStream_t)0);
-        void* tmp; hipMalloc(&tmp, bytes);
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        rocprim::radix_sort_pairs(tmp, bytes, a, b, vin, vout, n, 0u, 32u, (hipStream_t)0);
-        hipEventRecord(e0, 0);
-        for (int i = 0; i < 20; ++i) rocprim::radix_sort_pairs(tmp, bytes, a, b, vin, vout, n, 0u, 32u, (hipStream_t)0);
-        hipEventRecord(e1, 0); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("u32/u32 6M 32 bits           %.4f ms\n", ms / 20);
-    }
+    run<cfg<512, 16, 1024, 8, 9, R::match>>("1024x8 9b 44bits", kin, kout, vin, vout, m, 44);
+    run<cfg<512, 32, 1024, 8, 9, R::match>>("h512x32 1024x8 9b 44bits", kin, kout, vin, vout, m, 44);
+    run<cfg<512, 32, 1024, 9, 9, R::match>>("h512x32 1024x9 9b 44bits", kin, kout, vin, vout, m, 44);
+    run<cfg<512, 32, 1024, 10, 9, R::match>>("h512x32 1024x10 9b 44bits", kin, kout, vin, vout, m, 44);
+    run<cfg<512, 32, 1024, 12, 9, R::match>>("h512x32 1024x12 9b 44bits", kin, kout, vin, vout, m, 44);
+    run<cfg<1024, 16, 1024, 8, 9, R::match>>("h1024x16 1024x8 9b 44bits", kin, kout, vin, vout, m, 44);
+    run<cfg<512, 32, 1024, 8, 9, R::match>>("h512x32 1024x8 9b 47bits", kin, kout, vin, vout, m, 47);
+    run<cfg<512, 16, 512, 12, 8, R::match>>("512x12 8b 47bits", kin, kout, vin, vout, m, 47);
     return 0;
 }
