@@ -45,7 +45,7 @@ def algorithmic_bytes(st, kernel, end_bit):
     """SURVEY.md §8d byte model, per kernel launch."""
     N, V, M, T, P = (st[k] for k in ("num_particles", "num_visible", "num_intersections", "num_tiles", "num_pixels"))
     Ef, Eb = st["traversed_fwd"], st["traversed_bwd"]
-    b = math.ceil(end_bit / 8)
+    b = math.ceil(end_bit / 9)  # onesweep passes: 9-bit digits (csrc/gut_sort.hip)
     return {
         "project": (48 + 44) * N + 204 * V,
         "scan": 8 * N,
