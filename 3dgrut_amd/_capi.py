@@ -107,7 +107,7 @@ def load():
     fptr = C.POINTER(C.c_float)
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
-                                     C.c_float, C.c_float, C.c_float, u32, vp, vp]
+                                     C.c_float, C.c_float, C.c_float, u32, vp, vp, u32]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
     _lib = lib

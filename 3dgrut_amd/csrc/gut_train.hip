@@ -96,6 +96,7 @@ struct ShAdamParams {
     AdamParams a12, a48;
     const float* cam;  // device [views,3]: sensor positions in world space
     uint32_t n, views;
+    uint32_t view_stride;  // rows between consecutive views in mrgb (>= n)
     int32_t sh_degree;
     float grad_scale;
 };
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
             if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
             // --- rebuild the SH gradient of this Gaussian from the compact per-view rows ---
             for (uint32_t vw = 0; vw < sp.views; ++vw) {
-                const float* mr = mrgb + ((size_t)vw * sp.n + i) * 3;
+                const float* mr = mrgb + ((size_t)vw * sp.view_stride + i) * 3;
                 const float r = mr[0] * sp.grad_scale, g = mr[1] * sp.grad_scale, bl = mr[2] * sp.grad_scale;
                 if (r == 0.0f && g == 0.0f && bl == 0.0f) continue;
                 const float dx = px - sp.cam[3 * vw + 0], dy = py - sp.cam[3 * vw + 1], dz = pz - sp.cam[3 * vw + 2];
@@ -277,7 +278,8 @@ static void fill_adam(gut::AdamParams& ap, const float* lr, uint32_t cols, float
 int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* d_camera_positions,
                      const float* d_mrgb, const float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
                      float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
-                     float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out) {
+                     float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out,
+                     uint32_t mrgb_view_stride) {
     if (num_particles == 0) return 0;
     if (!d_camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
         !lr12 || !lr48)
@@ -288,6 +290,8 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
     fill_adam(sp.a48, lr48, 48, beta1, beta2, eps, step);
     sp.cam = d_camera_positions;
     sp.n = num_particles; sp.views = num_views; sp.sh_degree = sh_degree; sp.grad_scale = grad_scale;
+    sp.view_stride = mrgb_view_stride ? mrgb_view_stride : num_particles;
+    if (sp.view_stride < num_particles) return 3;
     hipLaunchKernelGGL(gut::k_sh_adam, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
                        static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<const float4*>(d_raw_grad12),
                        reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v),

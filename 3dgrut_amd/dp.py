@@ -93,3 +93,19 @@ def allgather_rows_(out, local, world: int, group=None):
         dist.all_gather(parts, local, group=group)
         for r, t in enumerate(parts):
             out[r].copy_(t)
+
+
+class _Done:
+    def wait(self):
+        return None
+
+
+def allgather_rows_async(out, local, world: int, group=None):
+    """out[world, rows, ...] <- every rank's `local` [rows, ...]; returns an object with .wait()."""
+    if _skip(world):
+        out[0].copy_(local)
+        return _Done()
+    if _stage_on_cpu(local, group):
+        allgather_rows_(out, local, world, group)
+        return _Done()
+    return dist.all_gather_into_tensor(out, local, group=group, async_op=True)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .dp import allgather_rows_, allreduce_max_, allreduce_mean_, allreduce_sum_async
+from .dp import allgather_rows_, allgather_rows_async, allreduce_max_, allreduce_mean_, allreduce_sum_async
 from .losses import photometric_loss
 from .tracer import SplatRaster, Tracer
 
@@ -77,7 +77,8 @@ class NativeGaussianModel:
 
 class NativeTrainStep:
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
-                 betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2):
+                 betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2,
+                 dp_chunks=4, dp_chunk_min_rows=1 << 20):
         self.model = model
         self.tracer = tracer
         self.raster: SplatRaster = tracer.tracer_wrapper
@@ -99,6 +100,7 @@ class NativeTrainStep:
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
         self.fused = bool(fused_sh_adam)
         self.fused_loss = bool(fused_loss)
+        self.dp_chunks, self.dp_chunk_min_rows = max(1, int(dp_chunks)), int(dp_chunk_min_rows)
         self.lambda_l1, self.lambda_ssim = float(lambda_l1), float(lambda_ssim)
         self._loss_ws = None
         self._loss3 = None
@@ -122,9 +124,18 @@ class NativeTrainStep:
         self.g12 = torch.empty((n, 12), dtype=torch.float32, device=dev)
         if self.fused:
             # compact exchange: per view only dL/dRGB (12 B per Gaussian) travels; the [N,48] SH gradient is rebuilt
-            # inside the fused SH-gradient + Adam kernel (csrc/gut_train.hip: k_sh_adam)
-            self.mrgb = torch.empty((max(1, self.world_size), n, 3), dtype=torch.float32, device=dev)
-            self.cams = torch.zeros((max(1, self.world_size), 3), dtype=torch.float32, device=dev)
+            # inside the fused SH-gradient + Adam kernel (csrc/gut_train.hip: k_sh_adam).  With more than one rank the
+            # Gaussians are split into row chunks (multiples of 256 rows = whole optimiser workgroups) that are exchanged
+            # and optimised as a pipeline; self.mrgb[c] is chunk c's gathered [world, rows_c, 3] block.
+            w = max(1, self.world_size)
+            nchunks = 1
+            if (w > 1 or getattr(self, "force_exchange", False)) and n >= self.dp_chunk_min_rows:
+                nchunks = self.dp_chunks
+            rows = (((n + nchunks - 1) // nchunks) + 255) // 256 * 256 if n else 0
+            self.chunks = [(r0, min(n, r0 + rows)) for r0 in range(0, n, rows)] if n else []
+            self.mrgb = [torch.empty((w, r1 - r0, 3), dtype=torch.float32, device=dev) for r0, r1 in self.chunks]
+            self.mrgb_local = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            self.cams = torch.zeros((w, 3), dtype=torch.float32, device=dev)
             self.g48 = None
         else:
             self.g48 = torch.empty((n, 48), dtype=torch.float32, device=dev)
@@ -240,33 +251,43 @@ class NativeTrainStep:
         vmask = None
         if self.fused:
             w = max(1, self.world_size)
-            self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, compact_radiance_grads=True,
-                                  out=(self.g12, self.mrgb[self.rank if w > 1 else 0]))
+            exchange = w > 1 or self.force_exchange
+            # this view's compact radiance gradient: directly view 0 of the gathered layout when there is nothing to gather
+            local_mrgb = self.mrgb_local if exchange else self.mrgb[0][0]
+            self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, compact_radiance_grads=True, out=(self.g12, local_mrgb))
             self._mark(evs)
             cam_local = self._sensor_position(batch)
             if self.post_backward_hook is not None:  # per-view statistics, before the exchange (strategy/gs.py:106-115)
                 self.post_backward_hook(self.g12[:, 0:3], cam_local)
-            if w > 1 or self.force_exchange:
-                work = allreduce_sum_async(self.g12, w)
-                allgather_rows_(self.mrgb, self.mrgb[self.rank], w)
+            works = []
+            if exchange:
+                # Chunk-pipelined exchange: the collectives of chunk c+1 run on RCCL's stream while the optimiser kernel
+                # of chunk c runs on the compute stream (the optimiser is HBM-bound, the exchange xGMI-bound).
                 allgather_rows_(self.cams, cam_local, w)
-                work.wait()
                 if self.selective:
                     allreduce_max_(vis, w)
+                for (r0, r1), gathered in zip(self.chunks, self.mrgb):
+                    works.append((allreduce_sum_async(self.g12[r0:r1], w),
+                                  allgather_rows_async(gathered, self.mrgb_local[r0:r1], w)))
             else:
                 self.cams[0].copy_(cam_local)
             if self.selective:
                 vmask = vis.reshape(-1)
             st = torch.cuda.current_stream(m.raw.device).cuda_stream
             f32p = C.POINTER(C.c_float)
-            rc = self._lib.gut_sh_adam_step(
-                C.c_void_p(st), m.num_gaussians, m.n_active_features, w, self.cams.data_ptr(), self.mrgb.data_ptr(),
-                self.g12.data_ptr(), 1.0 / w, m.raw.data_ptr(), self.m12.data_ptr(), self.v12.data_ptr(), m.features.data_ptr(),
-                self.m48.data_ptr(), self.v48.data_ptr(), self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p),
-                self.betas[0], self.betas[1], self.eps, 0 if self.selective else self.step_id + 1,
-                None if vmask is None else vmask.data_ptr(), self.act.data_ptr())
-            if rc:
-                raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
+            for k, ((r0, r1), gathered) in enumerate(zip(self.chunks, self.mrgb)):
+                if works:
+                    works[k][0].wait()
+                    works[k][1].wait()
+                rc = self._lib.gut_sh_adam_step(
+                    C.c_void_p(st), r1 - r0, m.n_active_features, w, self.cams.data_ptr(), gathered.data_ptr(),
+                    self.g12.data_ptr() + 48 * r0, 1.0 / w, m.raw.data_ptr() + 48 * r0, self.m12.data_ptr() + 48 * r0,
+                    self.v12.data_ptr() + 48 * r0, m.features.data_ptr() + 192 * r0, self.m48.data_ptr() + 192 * r0,
+                    self.v48.data_ptr() + 192 * r0, self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p),
+                    self.betas[0], self.betas[1], self.eps, 0 if self.selective else self.step_id + 1,
+                    None if vmask is None else vmask.data_ptr() + 4 * r0, self.act.data_ptr() + 48 * r0, r1 - r0)
+                if rc:
+                    raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
             # any in-place torch edit of raw (densification, MCMC noise, ...) bumps _version and forces a fresh activation
             self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
         else:

@@ -136,6 +136,11 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON line on
+    # stdout, so everything before that line is routed to stderr at the file-descriptor level
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if args.force_exchange and world == 1:
         os.environ["GUT_DP_FORCE_COLLECTIVES"] = "1"
@@ -264,7 +269,10 @@ def main():
             except Exception as e:  # the baseline is reported, never a gate
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -221,13 +221,16 @@ int gut_adam_step(void* stream, uint64_t rows, uint32_t cols, float* d_param, co
  * gradients are scaled by grad_scale (1/num_views for a mean over views).  pos is the pre-update position.
  * lr12/lr48: host arrays of per-column learning rates; step/visibility as in gut_adam_step.
  * d_act12_out (may be NULL): if given, every updated row's activation (what gut_activate_pack would compute from the new
- * raw row) is written there, so the next gut_trace needs no separate activation pass. */
+ * raw row) is written there, so the next gut_trace needs no separate activation pass.
+ * mrgb_view_stride: rows between consecutive views in d_mrgb (0 = num_particles).  All per-Gaussian pointers may be
+ * offset to a row range [r0, r1) with num_particles = r1 - r0: that is how the data-parallel trainer pipelines the
+ * optimiser over chunks of Gaussians behind the gradient exchange of the following chunk. */
 int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views,
                      const float* d_camera_positions /* device [num_views,3] */, const float* d_mrgb /* [num_views,N,3] */,
                      const float* d_raw_grad12, float grad_scale,
                      float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
                      const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
-                     const float* d_visibility, float* d_act12_out);
+                     const float* d_visibility, float* d_act12_out, uint32_t mrgb_view_stride);
 
 /* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */

@@ -349,3 +349,30 @@ def test_sorted_variant_backward(name, with_dist_grad):
         g = getattr(model, k).grad.cpu().numpy()
         err = rel_l2(g, e)
         assert err <= 2e-3, f"{name}/{k}: rel L2 {err}"
+
+
+def test_unusable_rays_do_not_poison_gradients():
+    """Rays with NaN / inf / zero directions never hit anything (oracle: every comparison with NaN is false).  The backward
+    evaluates non-hitting lanes with zero weights instead of masking them, so such lanes must be neutralised explicitly:
+    the gradients must stay finite and equal the oracle's for the same rays."""
+    mk, kind, W, H, (eye, tgt), kw = CASES["c1_pinhole_128"]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    rd = view["rd"].copy()
+    rd[40, 50] = np.nan
+    rd[41, 51] = (np.inf, 0.0, 1.0)
+    rd[64, 64] = 0.0
+    rd[10:12, 100:104] = np.nan
+    view = dict(view, rd=rd)
+    rng = np.random.default_rng(2)
+    rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
+    model0, d12, sph = _oracle_inputs(sc, 3)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    dens_g, sph_g, _ = oracle.backward(view["oracle_cam"], ref, rgba_grad, np.zeros((H, W, 1), np.float32))
+    assert np.isfinite(dens_g).all() and np.isfinite(sph_g).all()
+    res = _run_gpu(sc, view, 3, rgba_grad=rgba_grad, model=model0)
+    exp = _activated_grads(res["model"], dens_g, sph_g)
+    for k, e in exp.items():
+        g = getattr(res["model"], k).grad.cpu().numpy()
+        assert np.isfinite(g).all(), k
+        assert rel_l2(g, e) <= 2e-3, f"{k}: rel L2 {rel_l2(g, e)}"
