@@ -28,6 +28,9 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -636,6 +639,14 @@ void oracle_expand(const OracleParams* prm, int W, int H, uint32_t N,
 }
 
 /* higherMsb — gutRenderer.cu:79-94 (== bit_width for n >= 1) */
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 uint32_t oracle_higher_msb(uint32_t n) {
     uint32_t msb = 16, step = 16;
     while (step > 1) {
@@ -932,6 +943,9 @@ void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, 
     const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
     uint64_t traversed_total = 0;
     (void)dist;
+    /* tiles in parallel: the per-Gaussian double accumulators are shared, hence the atomic adds (their order, and with it the
+     * last bits of the double sums, depends on the thread schedule; every consumer compares with a tolerance) */
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : traversed_total)
     for (int tile = 0; tile < gx * gy; ++tile) {
         const int tx = tile % gx, ty = tile / gx;
         const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
@@ -984,6 +998,7 @@ void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, 
                     for (int c = 0; c < 3; ++c) {
                         const float fv = feat[3 * (size_t)id + c];
                         f[c] = fv > 0.0f ? fv : 0.0f;
+#pragma omp atomic
                         feat_grad[3 * (size_t)id + c] += (double)(rgb_g[c] * w);
                         rgb_run[c] += w * f[c];
                         const float rr = (Tn <= prm->min_transmittance) ? 0.0f : (rgb_final[c] - rgb_run[c]) / Tn;
@@ -1032,10 +1047,12 @@ void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, 
                     float q_b[4];
                     matmul_bw_quat(ray.d, g_rdr, q, q_b);
                     double* dg = density_grad + 12 * (size_t)id;
-                    dg[0] += (double)(-g_gposc[0]); dg[1] += (double)(-g_gposc[1]); dg[2] += (double)(-g_gposc[2]);
-                    dg[3] += (double)d_sigma;
-                    for (int c = 0; c < 4; ++c) dg[4 + c] += (double)(q_a[c] + q_b[c]);
-                    for (int c = 0; c < 3; ++c) dg[8 + c] += (double)d_scale[c];
+                    const double add[11] = {-g_gposc[0], -g_gposc[1], -g_gposc[2], d_sigma, q_a[0] + q_b[0], q_a[1] + q_b[1],
+                                            q_a[2] + q_b[2], q_a[3] + q_b[3], d_scale[0], d_scale[1], d_scale[2]};
+                    for (int c = 0; c < 11; ++c) {
+#pragma omp atomic
+                        dg[c] += add[c];
+                    }
                     T = Tn;
                     if (T < prm->min_transmittance) ray.alive = 0;
                 }
