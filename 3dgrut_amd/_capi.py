@@ -14,6 +14,7 @@ GUT_ABI_VERSION = 1
 GUT_NUM_KERNEL_TIMERS = 8
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
+BWD_SKIP_EPILOGUE = 4
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd")
 
 SHUTTER_GLOBAL = 4
@@ -58,7 +59,7 @@ class GutStats(C.Structure):
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
-           "gut_photometric_workspace_bytes", "gut_photometric_loss",
+           "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd",
            "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
 
 _lib = None
@@ -105,6 +106,8 @@ def load():
     lib.gut_adam_step.argtypes = [vp, C.c_uint64, u32, vp, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float,
                                   C.c_float, u32, vp]
     fptr = C.POINTER(C.c_float)
+    lib.gut_optimize_after_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float, u32,
+                                           vp, vp]
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
                                      C.c_float, C.c_float, C.c_float, u32, vp, vp, u32]

@@ -497,7 +497,7 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
     // the hit-distance gradient terms are then compiled out of the backward kernel
     if (!camera || !d_ray_origin || !d_ray_direction || !d_ray_radiance_density || !d_ray_radiance_density_grad)
         return fail("gut_trace_bwd: null pointer argument");
-    if (num_particles && (!d_particle_density || !d_particle_density_grad || !d_particle_radiance_grad))
+    if (num_particles && (!d_particle_density || (!(flags & GUT_BWD_SKIP_EPILOGUE) && (!d_particle_density_grad || !d_particle_radiance_grad))))
         return fail("gut_trace_bwd: null particle buffers");
     HIP_TRY(hipSetDevice(h->device));
     gut::ViewParams v;
@@ -531,7 +531,9 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
                                h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>());
     }
     mark(10);
-    if (flags & GUT_BWD_COMPACT_RADIANCE_GRADS)
+    if (flags & GUT_BWD_SKIP_EPILOGUE) {
+        // the caller folds the per-Gaussian epilogue into its optimiser step (gut_optimize_after_bwd)
+    } else if (flags & GUT_BWD_COMPACT_RADIANCE_GRADS)
         gut::launch_project_bwd_compact(s, n, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
                                         h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad);
     else
@@ -547,6 +549,28 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
     h->kev_bwd_valid = timing;
     if (timing) h->ring[h->ring_cur].bwd = true;
     h->have_backward = true;
+    return 0;
+}
+
+int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_features, const float* d_camera_position,
+                           float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
+                           const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
+                           const float* d_visibility, float* d_act12_out) {
+    if (!h) return fail("gut_optimize_after_bwd: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (!h->have_backward || h->fwd_stream != s)
+        return fail("gut_optimize_after_bwd: no backward context on this stream (call gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) first)");
+    if (num_active_features != h->sh_degree) return fail("gut_optimize_after_bwd: sh degree differs from the cached forward");
+    if (h->n == 0) return 0;
+    if (!d_camera_position || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48)
+        return fail("gut_optimize_after_bwd: null pointer argument");
+    HIP_TRY(hipSetDevice(h->device));
+    gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, d_camera_position, h->grad16.as<float>(), h->tiles_count.as<uint32_t>(),
+                                     h->feat.as<float>(), d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12, lr48, beta1, beta2,
+                                     eps, step, d_visibility, d_act12_out);
+    HIP_TRY(hipGetLastError());
+    h->have_backward = false;  // the gradient rows are consumed
     return 0;
 }
 

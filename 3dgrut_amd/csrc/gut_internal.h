@@ -85,6 +85,11 @@ void launch_render_sorted_bwd(hipStream_t s, const ViewParams& v, const RenderCo
                               const float* dist_grad, float* grad16);
 void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density12, const uint32_t* tiles_count,
                                 const float* feat, const float* grad16, float* raw_grad12, float* mrgb);
+// fused per-Gaussian backward epilogue + SH-gradient + Adam (gut_train.hip), single view, reads the handle's gradient rows
+void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const float* d_camera_position, const float* grad16,
+                                 const uint32_t* tiles_count, const float* feat, float* raw12, float* raw_m, float* raw_v,
+                                 float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
+                                 float eps, uint32_t step, const float* visibility, float* act12_out);
 void launch_stats_reduce(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint32_t t, const uint32_t* trav_fwd,
                          const uint32_t* trav_bwd, Counters* out);
 

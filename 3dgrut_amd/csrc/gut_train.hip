@@ -135,11 +135,17 @@ __device__ __forceinline__ void adam4(const AdamParams& ap, uint32_t c0, const f
 #undef GUT_ADAM_LANE
 }
 
+// kScratch = true (one view, no exchange): the per-Gaussian epilogue of the backward (K8c) is folded in — grad12 then points
+// at the renderer's 64-byte gradient rows [pos3, density, quat4, scale3, rgb3, pad2] w.r.t. the ACTIVATED parameters, which
+// are chained to the raw parameters here (the activations are recomputed from the raw row the optimiser loads anyway, with
+// the very function that produced the forward's inputs), and the masked dL/dRGB never leaves registers.
+template <bool kScratch>
 __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float* __restrict__ mrgb,
                                                    const float4* __restrict__ grad12, float4* __restrict__ p12,
                                                    float4* __restrict__ m12, float4* __restrict__ v12, float4* __restrict__ p48,
                                                    float4* __restrict__ m48, float4* __restrict__ v48,
-                                                   const float* __restrict__ visibility, float4* __restrict__ act12) {
+                                                   const float* __restrict__ visibility, float4* __restrict__ act12,
+                                                   const uint32_t* __restrict__ tiles_count, const float* __restrict__ feat) {
     constexpr int kRow = 49;
     __shared__ float tile[(kBlock / 64) * 64 * kRow];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -158,8 +164,31 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
         if (active) {
             // --- raw [N,12] row ---
             float4 b = p12[3 * (size_t)i + 1], c = p12[3 * (size_t)i + 2];
-            float4 g0 = grad12[3 * (size_t)i + 0], g1 = grad12[3 * (size_t)i + 1], g2 = grad12[3 * (size_t)i + 2];
+            float4 g0, g1, g2;
+            float own_r = 0.f, own_g = 0.f, own_b = 0.f;  // kScratch: this view's masked dL/dRGB
             const float gs = sp.grad_scale;
+            if (kScratch) {
+                g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
+                if (tiles_count[i] != 0) {
+                    g0 = grad12[4 * (size_t)i + 0];
+                    g1 = grad12[4 * (size_t)i + 1];
+                    g2 = grad12[4 * (size_t)i + 2];
+                    const float4 g3 = grad12[4 * (size_t)i + 3];
+                    own_r = feat[3 * (size_t)i + 0] > 0.0f ? g2.w : 0.0f;
+                    own_g = feat[3 * (size_t)i + 1] > 0.0f ? g3.x : 0.0f;
+                    own_b = feat[3 * (size_t)i + 2] > 0.0f ? g3.y : 0.0f;
+                    float4 act[3];
+                    activate_row(a, b, c, act);
+                    g0.w = g0.w * act[0].w * (1.0f - act[0].w);                      // sigmoid
+                    const float dot = g1.x * act[1].x + g1.y * act[1].y + g1.z * act[1].z + g1.w * act[1].w;
+                    const float inv = 1.0f / act[2].w;                                // 1 / |quat|
+                    g1 = make_float4((g1.x - act[1].x * dot) * inv, (g1.y - act[1].y * dot) * inv, (g1.z - act[1].z * dot) * inv,
+                                     (g1.w - act[1].w * dot) * inv);                  // normalise
+                    g2.x *= act[2].x; g2.y *= act[2].y; g2.z *= act[2].z;             // exp
+                }
+            } else {
+                g0 = grad12[3 * (size_t)i + 0]; g1 = grad12[3 * (size_t)i + 1]; g2 = grad12[3 * (size_t)i + 2];
+            }
             g0.x *= gs; g0.y *= gs; g0.z *= gs; g0.w *= gs; g1.x *= gs; g1.y *= gs; g1.z *= gs; g1.w *= gs;
             g2.x *= gs; g2.y *= gs; g2.z *= gs; g2.w = 0.0f;
             float4 ma = m12[3 * (size_t)i + 0], mb = m12[3 * (size_t)i + 1], mc = m12[3 * (size_t)i + 2];
@@ -175,8 +204,13 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
             if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
             // --- rebuild the SH gradient of this Gaussian from the compact per-view rows ---
             for (uint32_t vw = 0; vw < sp.views; ++vw) {
-                const float* mr = mrgb + ((size_t)vw * sp.view_stride + i) * 3;
-                const float r = mr[0] * sp.grad_scale, g = mr[1] * sp.grad_scale, bl = mr[2] * sp.grad_scale;
+                float r, g, bl;
+                if (kScratch) {
+                    r = own_r * sp.grad_scale; g = own_g * sp.grad_scale; bl = own_b * sp.grad_scale;
+                } else {
+                    const float* mr = mrgb + ((size_t)vw * sp.view_stride + i) * 3;
+                    r = mr[0] * sp.grad_scale; g = mr[1] * sp.grad_scale; bl = mr[2] * sp.grad_scale;
+                }
                 if (r == 0.0f && g == 0.0f && bl == 0.0f) continue;
                 const float dx = px - sp.cam[3 * vw + 0], dy = py - sp.cam[3 * vw + 1], dz = pz - sp.cam[3 * vw + 2];
                 const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -216,6 +250,35 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
     }
 }
 
+}  // namespace gut
+
+static void fill_adam(gut::AdamParams& ap, const float* lr, uint32_t cols, float beta1, float beta2, float eps, uint32_t step) {
+    for (uint32_t i = 0; i < 64; ++i) ap.lr[i] = i < cols ? lr[i] : 0.0f;
+    ap.beta1 = beta1; ap.beta2 = beta2; ap.eps = eps; ap.cols = cols;
+    if (step) {
+        ap.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
+        ap.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    } else {
+        ap.bias1 = 1.0f; ap.bias2_sqrt = 1.0f;
+    }
+}
+
+namespace gut {
+void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const float* d_camera_position, const float* grad16,
+                                 const uint32_t* tiles_count, const float* feat, float* raw12, float* raw_m, float* raw_v,
+                                 float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
+                                 float eps, uint32_t step, const float* visibility, float* act12_out) {
+    if (n == 0) return;
+    ShAdamParams sp;
+    fill_adam(sp.a12, lr12, 12, beta1, beta2, eps, step);
+    fill_adam(sp.a48, lr48, 48, beta1, beta2, eps, step);
+    sp.cam = d_camera_position;
+    sp.n = n; sp.views = 1; sp.sh_degree = sh_degree; sp.grad_scale = 1.0f; sp.view_stride = n;
+    hipLaunchKernelGGL(k_sh_adam<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sp, (const float*)nullptr,
+                       reinterpret_cast<const float4*>(grad16), reinterpret_cast<float4*>(raw12), reinterpret_cast<float4*>(raw_m),
+                       reinterpret_cast<float4*>(raw_v), reinterpret_cast<float4*>(sh48), reinterpret_cast<float4*>(sh_m),
+                       reinterpret_cast<float4*>(sh_v), visibility, reinterpret_cast<float4*>(act12_out), tiles_count, feat);
+}
 }  // namespace gut
 
 extern "C" {
@@ -264,16 +327,6 @@ int gut_mcmc_relocation(void* stream, int32_t n, const float* d_opacities, const
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-static void fill_adam(gut::AdamParams& ap, const float* lr, uint32_t cols, float beta1, float beta2, float eps, uint32_t step) {
-    for (uint32_t i = 0; i < 64; ++i) ap.lr[i] = i < cols ? lr[i] : 0.0f;
-    ap.beta1 = beta1; ap.beta2 = beta2; ap.eps = eps; ap.cols = cols;
-    if (step) {
-        ap.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
-        ap.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    } else {
-        ap.bias1 = 1.0f; ap.bias2_sqrt = 1.0f;
-    }
-}
 
 int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* d_camera_positions,
                      const float* d_mrgb, const float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
@@ -292,11 +345,11 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
     sp.n = num_particles; sp.views = num_views; sp.sh_degree = sh_degree; sp.grad_scale = grad_scale;
     sp.view_stride = mrgb_view_stride ? mrgb_view_stride : num_particles;
     if (sp.view_stride < num_particles) return 3;
-    hipLaunchKernelGGL(gut::k_sh_adam, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
+    hipLaunchKernelGGL(gut::k_sh_adam<false>, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
                        static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<const float4*>(d_raw_grad12),
                        reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v),
                        reinterpret_cast<float4*>(d_sh48), reinterpret_cast<float4*>(d_sh_m), reinterpret_cast<float4*>(d_sh_v),
-                       d_visibility, reinterpret_cast<float4*>(d_act12_out));
+                       d_visibility, reinterpret_cast<float4*>(d_act12_out), (const uint32_t*)nullptr, (const float*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -78,7 +78,7 @@ class NativeGaussianModel:
 class NativeTrainStep:
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
                  betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2,
-                 dp_chunks=4, dp_chunk_min_rows=1 << 20):
+                 dp_chunks=4, dp_chunk_min_rows=1 << 20, fuse_epilogue=True):
         self.model = model
         self.tracer = tracer
         self.raster: SplatRaster = tracer.tracer_wrapper
@@ -100,6 +100,7 @@ class NativeTrainStep:
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
         self.fused = bool(fused_sh_adam)
         self.fused_loss = bool(fused_loss)
+        self.fuse_epilogue = bool(fuse_epilogue)
         self.dp_chunks, self.dp_chunk_min_rows = max(1, int(dp_chunks)), int(dp_chunk_min_rows)
         self.lambda_l1, self.lambda_ssim = float(lambda_l1), float(lambda_ssim)
         self._loss_ws = None
@@ -252,6 +253,21 @@ class NativeTrainStep:
         if self.fused:
             w = max(1, self.world_size)
             exchange = w > 1 or self.force_exchange
+            if not exchange and self.post_backward_hook is None and self.fuse_epilogue:
+                # one view, nobody else needs the per-Gaussian gradients: K8's epilogue, the SH-gradient rebuild and Adam run
+                # as ONE pass over the Gaussians, straight from the renderer's gradient rows (gut_optimize_after_bwd)
+                self.raster.trace_bwd(*bwd_args, skip_epilogue=True)
+                self._mark(evs)
+                vmask = vis.reshape(-1) if self.selective else None
+                self.raster.optimize_after_bwd(m.n_active_features, self._sensor_position(batch), m.raw, self.m12, self.v12, m.features,
+                                               self.m48, self.v48, self.lr12, self.lr48, self.betas, self.eps,
+                                               0 if self.selective else self.step_id + 1, vmask, self.act)
+                self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
+                self._mark(evs)
+                if evs is not None:
+                    self._phase_events.append(evs)
+                self.step_id += 1
+                return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
             # this view's compact radiance gradient: directly view 0 of the gathered layout when there is nothing to gather
             local_mrgb = self.mrgb_local if exchange else self.mrgb[0][0]
             self.raster.trace_bwd(*bwd_args, raw_parameter_grads=True, compact_radiance_grads=True, out=(self.g12, local_mrgb))

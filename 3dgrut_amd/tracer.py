@@ -203,7 +203,8 @@ class SplatRaster:
 
     def trace_bwd(self, frame_number, num_active_features, particle_density, particle_radiance, ray_ori, ray_dir, ray_time,
                   sensor_params, ts_start, ts_end, pose_start, pose_end, ray_radiance_density, ray_radiance_density_grd,
-                  ray_hit_distance, ray_hit_distance_grd, raw_parameter_grads=False, compact_radiance_grads=False, out=None):
+                  ray_hit_distance, ray_hit_distance_grd, raw_parameter_grads=False, compact_radiance_grads=False, out=None,
+                  skip_epilogue=False):
         ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
         ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
         H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
@@ -214,7 +215,9 @@ class SplatRaster:
         dist = _check_f32_cuda(ray_hit_distance, "rayHitDistance")
         dist_g = None if ray_hit_distance_grd is None else _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
         opts = dict(dtype=torch.float32, device=dev)
-        if out is not None:
+        if skip_epilogue:   # gradient rows stay in the handle for optimize_after_bwd (native trainer, one view)
+            dens_g = sph_g = None
+        elif out is not None:
             dens_g, sph_g = out
         else:
             dens_g = torch.empty((n, 12), **opts)  # fully written by the per-Gaussian epilogue kernel
@@ -230,12 +233,28 @@ class SplatRaster:
                                          particle_density.data_ptr() if n else None,
                                          particle_radiance.data_ptr() if n else None, W, H, ray_ori.data_ptr(),
                                          ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(), rgba_g.data_ptr(),
-                                         dist.data_ptr(), None if dist_g is None else dist_g.data_ptr(), dens_g.data_ptr() if n else None,
-                                         sph_g.data_ptr() if n else None,
+                                         dist.data_ptr(), None if dist_g is None else dist_g.data_ptr(),
+                                         dens_g.data_ptr() if (n and dens_g is not None) else None,
+                                         sph_g.data_ptr() if (n and sph_g is not None) else None,
                                          (_capi.BWD_RAW_PARAMETER_GRADS if raw_parameter_grads else 0) |
-                                         (_capi.BWD_COMPACT_RADIANCE_GRADS if compact_radiance_grads else 0))
+                                         (_capi.BWD_COMPACT_RADIANCE_GRADS if compact_radiance_grads else 0) |
+                                         (_capi.BWD_SKIP_EPILOGUE if skip_epilogue else 0))
         _capi.check(rc, "trace_bwd")
         return dens_g, sph_g
+
+    def optimize_after_bwd(self, num_active_features, camera_position, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps,
+                           step, visibility=None, act_out=None):
+        """Per-Gaussian backward epilogue + SH-gradient rebuild + Adam in one pass (gut_optimize_after_bwd); follows a
+        trace_bwd(..., skip_epilogue=True) on the same stream.  lr12 / lr48: float32 numpy arrays."""
+        f32p = C.POINTER(C.c_float)
+        stream = torch.cuda.current_stream(raw12.device).cuda_stream
+        with torch.cuda.device(raw12.device):
+            rc = self._lib.gut_optimize_after_bwd(self._handle, C.c_void_p(stream), int(num_active_features), camera_position.data_ptr(),
+                                                  raw12.data_ptr(), raw_m.data_ptr(), raw_v.data_ptr(), sh48.data_ptr(), sh_m.data_ptr(),
+                                                  sh_v.data_ptr(), lr12.ctypes.data_as(f32p), lr48.ctypes.data_as(f32p), betas[0],
+                                                  betas[1], eps, int(step), None if visibility is None else visibility.data_ptr(),
+                                                  None if act_out is None else act_out.data_ptr())
+        _capi.check(rc, "optimize_after_bwd")
 
     def collect_times(self):
         f, b = C.c_float(-1.0), C.c_float(-1.0)

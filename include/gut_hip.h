@@ -152,6 +152,10 @@ int gut_trace_bwd(gut_handle h, void* stream, uint32_t frame_number, int32_t num
  * dL/dRGB masked by (precomputed RGB > 0) instead of the [N,48] SH gradient; the SH gradient of the view is
  * Y_k(dir) (x) that row and is rebuilt by gut_sh_adam_step (also across several views: compact data-parallel exchange). */
 #define GUT_BWD_COMPACT_RADIANCE_GRADS 2u
+/* GUT_BWD_SKIP_EPILOGUE: stop after the compositing backward; the per-Gaussian gradient rows stay in the handle and the two
+ * output pointers may be NULL.  Follow with gut_optimize_after_bwd on the same stream (single-view training step: the
+ * epilogue, the SH-gradient rebuild and Adam then run as ONE pass over the Gaussians). */
+#define GUT_BWD_SKIP_EPILOGUE 4u
 int gut_trace_bwd_ex(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features,
                      uint32_t num_particles, const float* d_particle_density, const float* d_particle_radiance,
                      int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
@@ -231,6 +235,16 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
                      float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
                      const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
                      const float* d_visibility, float* d_act12_out, uint32_t mrgb_view_stride);
+
+/* Epilogue of the last gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) + gut_sh_adam_step for ONE view in a single kernel:
+ * chains the handle's gradient rows to the raw parameters (sigmoid / normalise / exp recomputed from d_raw12, which must be
+ * the rows the forward's gut_activate_pack input was made from), rebuilds the SH gradient from the masked dL/dRGB and
+ * applies Adam to d_raw12 / d_sh48.  d_camera_position: device [3] sensor position of the view.  Other arguments as in
+ * gut_sh_adam_step.  Consumes the backward context. */
+int gut_optimize_after_bwd(gut_handle h, void* stream, int32_t num_active_features, const float* d_camera_position,
+                           float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
+                           const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
+                           const float* d_visibility, float* d_act12_out);
 
 /* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */

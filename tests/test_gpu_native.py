@@ -58,9 +58,12 @@ def test_selective_adam_semantics():
     assert rel_l2(p[0::2].cpu().numpy(), exp[0::2].cpu().numpy()) <= 1e-6
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("mode", ["dense", "compact", "one_pass"])
 @pytest.mark.parametrize("steps", [1, 3])
-def test_native_step_matches_autograd_step(steps, fused):
+def test_native_step_matches_autograd_step(steps, mode):
+    """dense: K8 writes [N,12]+[N,48], two Adam launches; compact: K8c + fused SH-gradient/Adam kernel (the data-parallel
+    layout); one_pass: epilogue + SH gradient + Adam in one kernel straight from the renderer's gradient rows."""
+    fused = mode != "dense"
     sc = scenes.scene_c1(800, 21)
     view = make_view("pinhole", 96, 80, cams.look_at_c2w((0.2, -0.1, -3.5), (0, 0, 0)), fx=90)
     batch = to_batch(view, DEV)
@@ -70,7 +73,8 @@ def test_native_step_matches_autograd_step(steps, fused):
     ta = train.TrainStep(ma, gut.Tracer({"render": {}}), scene_extent=1.0)
     # native path
     mn = native.NativeGaussianModel(sc, device=DEV)
-    tn = native.NativeTrainStep(mn, gut.Tracer({"render": {}}), scene_extent=1.0, fused_sh_adam=fused)
+    tn = native.NativeTrainStep(mn, gut.Tracer({"render": {}}), scene_extent=1.0, fused_sh_adam=fused,
+                                fuse_epilogue=(mode == "one_pass"))
     for _ in range(steps):
         la, _ = ta.step(batch)
         ln, _ = tn.step(batch)
