@@ -11,11 +11,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  # override: dev experiments only
 
 GUT_ABI_VERSION = 1
-GUT_NUM_KERNEL_TIMERS = 8
+GUT_NUM_KERNEL_TIMERS = 9
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
 BWD_SKIP_EPILOGUE = 4
-KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd")
+KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer")
 
 SHUTTER_GLOBAL = 4
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1

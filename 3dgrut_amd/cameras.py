@@ -56,14 +56,26 @@ def fisheye_max_angle(W, H, fx, fy, cx, cy):
     return max(2.0 * max_radius / fx, 2.0 * max_radius / fy) / 2.0
 
 
-def fisheye_rays(W, H, fx, fy, cx=None, cy=None):
-    """Equidistant fisheye (radial coeffs 0): theta = |normalized image point|."""
+def fisheye_rays(W, H, fx, fy, cx=None, cy=None, radial=None, newton_iterations=3):
+    """OpenCV fisheye rays.  radial = (k1..k4) of the forward polynomial delta = theta (1 + k1 theta^2 + ... + k4 theta^8);
+    it is inverted per pixel with Newton steps from the linear (equidistant) initial guess, as
+    camera_models.py:156-235 does (3 iterations).  With zero coefficients theta = delta exactly."""
     cx = W / 2 if cx is None else cx
     cy = H / 2 if cy is None else cy
     x, y = np.meshgrid(np.arange(W, dtype=np.float64) + 0.5, np.arange(H, dtype=np.float64) + 0.5, indexing="xy")
     nx, ny = (x - cx) / fx, (y - cy) / fy
     delta = np.sqrt(nx * nx + ny * ny)
     theta = delta
+    if radial is not None and np.any(np.asarray(radial, np.float64) != 0.0):
+        k1, k2, k3, k4 = [float(k) for k in np.asarray(radial, np.float64)[:4]]
+        max_angle = fisheye_max_angle(W, H, fx, fy, cx, cy)
+        max_norm_dist = max(W / 2 / fx, H / 2 / fy)
+        theta = delta * (max_angle / max_norm_dist)
+        for _ in range(newton_iterations):
+            t2 = theta * theta
+            f = theta * (1.0 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)))) - delta
+            df = 1.0 + t2 * (3 * k1 + t2 * (5 * k2 + t2 * (7 * k3 + t2 * 9 * k4)))
+            theta = theta - f / df
     s = np.sin(theta) / np.maximum(delta, 1e-6)
     d = np.stack((s * nx, s * ny, np.cos(theta)), axis=-1)
     d[delta < 1e-6] = (0.0, 0.0, 1.0)

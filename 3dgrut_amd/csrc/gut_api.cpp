@@ -124,6 +124,9 @@ struct gut_context {
     DevBuf ranges, trav_fwd, trav_bwd, tile_order;  // per-tile traversal depths (statistics)
     DevBuf counters;
     uint32_t* host_count = nullptr;  // pinned
+    hipEvent_t count_event = nullptr;  // the count read-back has landed (work queued behind it keeps the GPU busy meanwhile)
+    bool trains = false;               // a backward has run on this handle: forwards pre-clear the gradient rows
+    bool grad16_clean = false;         // ... and this says the rows are already zero when the backward starts
 
     // cached forward context (gutRenderer.cu:252-254, 413)
     bool have_forward = false;
@@ -139,8 +142,8 @@ struct gut_context {
     // per-kernel event boundaries: a ring of sets so that bench.py can average over its whole timed region
     static constexpr int kRing = 64;
     struct KevSet {
-        hipEvent_t e[12] = {};
-        bool fwd = false, bwd = false;
+        hipEvent_t e[14] = {};
+        bool fwd = false, bwd = false, opt = false;
     };
     KevSet ring[kRing];
     int ring_cur = 0;    // set used by the most recent trace()
@@ -325,6 +328,7 @@ void gut_destroy(gut_handle h) {
                       &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
+    if (h->count_event) (void)hipEventDestroy(h->count_event);
     (void)drain_timers(h->fwd_timers);
     (void)drain_timers(h->bwd_timers);
     for (auto& set : h->ring)
@@ -378,6 +382,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
         h->kev = h->ring[h->ring_cur].e;
         h->ring[h->ring_cur].fwd = false;
         h->ring[h->ring_cur].bwd = false;
+        h->ring[h->ring_cur].opt = false;
     }
     auto mark = [&](int i) {
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
@@ -395,12 +400,24 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
         HIP_TRY(gut::run_scan(s, h->scan_temp.p, h->scan_temp.cap, h->tiles_count.as<uint32_t>(), h->tiles_offset.as<uint32_t>(), n));
         // intersection count readback: the one host sync of the path (gutRenderer.cu:313-321)
         HIP_TRY(hipMemcpyAsync(h->host_count, h->tiles_offset.as<uint32_t>() + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        if (!h->count_event) HIP_TRY(hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h->count_event, s));
+        // work that does not depend on the count is queued BEHIND the read-back and runs while the host waits for it:
+        // the tile-range clear and, on a handle that trains, the clear of the 64-byte gradient rows of the coming backward
+        HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
+        h->grad16_clean = false;
+        if (h->trains) {
+            HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)n));
+            HIP_TRY(hipMemsetAsync(h->grad16.p, 0, sizeof(float) * 16 * (size_t)n, s));
+            h->grad16_clean = true;
+        }
+        HIP_TRY(hipEventSynchronize(h->count_event));
         m = *h->host_count;
+    } else {
+        HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
     }
     mark(2);
     const int end_bit = 32 + (int)bit_width_u32((uint32_t)tiles);
-    HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
     if (m) {
         HIP_TRY(h->keys_unsorted.ensure(sizeof(uint64_t) * (size_t)m));
         HIP_TRY(h->keys_sorted.ensure(sizeof(uint64_t) * (size_t)m));
@@ -514,7 +531,9 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
     };
     mark(8);
-    HIP_TRY(hipMemsetAsync(h->grad16.p, 0, sizeof(float) * 16 * (size_t)n, s));
+    if (!h->grad16_clean) HIP_TRY(hipMemsetAsync(h->grad16.p, 0, sizeof(float) * 16 * (size_t)n, s));
+    h->grad16_clean = false;
+    h->trains = true;
     mark(9);
     if (h->m && h->cfg.k_buffer_size > 0) {
         if (!d_ray_hit_distance) return fail("gut_trace_bwd: the sorted variant needs d_ray_hit_distance");
@@ -566,10 +585,16 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     if (!d_camera_position || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48)
         return fail("gut_optimize_after_bwd: null pointer argument");
     HIP_TRY(hipSetDevice(h->device));
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[12] && h->kev[13];
+    if (timing) (void)hipEventRecord(h->kev[12], s);
     gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, d_camera_position, h->grad16.as<float>(), h->tiles_count.as<uint32_t>(),
                                      h->feat.as<float>(), d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12, lr48, beta1, beta2,
                                      eps, step, d_visibility, d_act12_out);
     HIP_TRY(hipGetLastError());
+    if (timing) {
+        (void)hipEventRecord(h->kev[13], s);
+        h->ring[h->ring_cur].opt = true;
+    }
     h->have_backward = false;  // the gradient rows are consumed
     return 0;
 }
@@ -608,6 +633,7 @@ int gut_kernel_times(gut_handle h, float* ms8) {
         ms8[6] = span(9, 10);   // render backward
         ms8[7] = span(10, 11);  // project backward
     }
+    if (h->ring[h->ring_cur].opt) ms8[8] = span(12, 13);  // one-pass optimiser (gut_optimize_after_bwd)
     return 0;
 }
 
@@ -617,12 +643,12 @@ int gut_kernel_times_mean(gut_handle h, float* ms8, int32_t* count) {
     if (!h->cfg.enable_kernel_timings) return fail("gut_kernel_times_mean: enable_kernel_timings is off");
     double sum[GUT_NUM_KERNEL_TIMERS] = {};
     int cnt[GUT_NUM_KERNEL_TIMERS] = {};
-    static const int kA[GUT_NUM_KERNEL_TIMERS] = {0, 1, 2, 3, 4, 5, 9, 10};
-    static const int kB[GUT_NUM_KERNEL_TIMERS] = {1, 2, 3, 4, 5, 6, 10, 11};
+    static const int kA[GUT_NUM_KERNEL_TIMERS] = {0, 1, 2, 3, 4, 5, 9, 10, 12};
+    static const int kB[GUT_NUM_KERNEL_TIMERS] = {1, 2, 3, 4, 5, 6, 10, 11, 13};
     for (int k = 0; k < h->ring_count; ++k) {
         const auto& set = h->ring[(h->ring_cur - k + 2 * gut_context::kRing) % gut_context::kRing];
         for (int i = 0; i < GUT_NUM_KERNEL_TIMERS; ++i) {
-            const bool ok = i < 6 ? set.fwd : set.bwd;
+            const bool ok = i < 6 ? set.fwd : (i < 8 ? set.bwd : set.opt);
             if (!ok || !set.e[kA[i]] || !set.e[kB[i]]) continue;
             float ms = 0.f;
             if (hipEventSynchronize(set.e[kB[i]]) == hipSuccess && hipEventElapsedTime(&ms, set.e[kA[i]], set.e[kB[i]]) == hipSuccess) {

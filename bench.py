@@ -55,6 +55,9 @@ def algorithmic_bytes(st, kernel, end_bit):
         "render": 8 * T + 64 * Ef + 48 * P,
         "render_bwd": 8 * T + 64 * Eb + 64 * P + 112 * V,
         "project_bwd": (40 + 384) * V + 252 * N,
+        # one-pass optimiser (k_sh_adam<scratch>): raw p/m/v in+out 288, next activation 48, SH p/m/v in+out 1152, count 4 per
+        # Gaussian; 64-byte gradient row + 12-byte RGB per Gaussian with tiles
+        "optimizer": 1492 * N + 76 * V,
     }[kernel]
 
 
@@ -225,6 +228,16 @@ def main():
         ms_per_step = 1000.0 * elapsed / args.steps
         value = world * args.steps / elapsed
         dom = max((k for k in ktimes if ktimes[k] > 0), key=lambda k: ktimes[k])
+        # achievable HBM bandwidth of THIS box, for context next to the 8 TB/s spec: device-to-device copy of 2 GB
+        a = torch.empty(1 << 29, dtype=torch.float32, device=dev); b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize(dev)
+        copy_gbs = 4 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
         abytes = algorithmic_bytes(stats, dom, stats["sort_end_bit"])
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same workload only)
@@ -236,7 +249,7 @@ def main():
             traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
-                    "mean_launch_ms": ktimes[dom], "launches_averaged": kcount}
+                    "mean_launch_ms": ktimes[dom], "launches_averaged": kcount, "box_copy_GBps": copy_gbs}
         per_kernel = {k: {"ms": ktimes[k], "GBps": (algorithmic_bytes(stats, k, stats["sort_end_bit"]) / (ktimes[k] * 1e-3) / 1e9) if ktimes[k] > 0 else None}
                       for k in ktimes}
         out = {

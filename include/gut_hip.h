@@ -176,9 +176,9 @@ int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes);
 int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
 
 /* per-kernel hipEvent timings of the last trace / trace_bwd (ms), for bench.py's roofline block.
- * Order: project, scan, expand, sort, ranges, render, render_bwd, project_bwd.  Requires
- * enable_kernel_timings; synchronises. */
-#define GUT_NUM_KERNEL_TIMERS 8
+ * Order: project, scan, expand, sort, ranges, render, render_bwd, project_bwd, optimizer (gut_optimize_after_bwd; -1 when
+ * that call was not used).  Requires enable_kernel_timings; synchronises. */
+#define GUT_NUM_KERNEL_TIMERS 9
 int gut_kernel_times(gut_handle h, float* ms8);
 /* mean per-kernel time over the (at most 64 most recent) trace/trace_bwd calls since the previous call of this
  * function; *count = number of forward calls averaged.  Synchronises. */

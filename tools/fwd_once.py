@@ -9,13 +9,22 @@ W, H, fx = 1237, 822, 1040.0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 bwd = len(sys.argv) > 3 and sys.argv[3] == "bwd"
+step = len(sys.argv) > 3 and sys.argv[3] == "step"   # full native train steps (incl. the one-pass optimiser kernel)
 ro, rd = cams.pinhole_rays(W, H, fx, fx); K = cams.pinhole_intrinsics_dict(W, H, fx, fx)
 sc = scenes.scene_outdoor_like(n=n, seed=2)
 model = model_mod.GaussianModel(sc, device=dev)
 tr = gut.Tracer({"render": {"enable_kernel_timings": True}})
 b = gut.Batch(rays_ori=torch.as_tensor(ro, device=dev), rays_dir=torch.as_tensor(rd, device=dev),
               T_to_world=torch.as_tensor(cams.orbit_c2w(4.5, 7.0, 12.0), device=dev)[None], intrinsics_OpenCVPinholeCameraModelParameters=K)
-for _ in range(iters):
+if step:
+    native = importlib.import_module("3dgrut_amd.native")
+    nm = native.NativeGaussianModel(sc, device=dev)
+    ts = native.NativeTrainStep(nm, tr, scene_extent=5.0)
+    b.T_to_world = b.T_to_world.cpu()
+    b.rgb_gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(1)).to(dev)
+    for _ in range(iters):
+        ts.step(b)
+for _ in range(0 if step else iters):
     if bwd:
         out = tr.render(model, b, train=True)
         (out["pred_rgb"].mean() + out["pred_opacity"].mean()).backward()
