@@ -5,7 +5,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/profiles
-rm -rf "$OUT"; mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"   # NB: also delete gpurun_out/profiles locally before the call (gpurun merges, it does not mirror)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --steps 20 --warmup 5 \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err" || exit 1
