@@ -50,7 +50,8 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 // ---------------------------------------------------------------------------------------------------
 // K6 forward
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c, const float4* __restrict__ density12,
+// (5 waves per SIMD: at the 103 VGPRs the compiler takes otherwise the kernel runs 7 % slower, at 6 it spills)
+__global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts c, const float4* __restrict__ density12,
                                                   const float* __restrict__ feat, const float* __restrict__ ray_ori,
                                                   const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
                                                   const uint32_t* __restrict__ sorted_ids, uint32_t num_intersections,
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                                                   float* __restrict__ hits, uint32_t* __restrict__ tile_traversed) {
     __shared__ FwdEntry stage[kBlock];
     __shared__ uint32_t s_deepest, s_first_invalid;
+    __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (16x4 strips) can hit it at all
+    __shared__ uint16_t s_list[kBlock / 64][kBlock];  // per wave: the staged entries it has to evaluate (index), in list order
+    __shared__ StripPlanes s_planes;
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -74,6 +78,8 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
         s_first_invalid = kBlock;
     }
     const bool centred = __syncthreads_and(ray.centred ? 1 : 0) != 0;  // block-uniform
+    build_strip_planes(s_planes, ray, inside, centred, tid);
+    const uint32_t wave_bit = 1u << (tid >> 6);
 
     const uint2 range = ranges[tile];
     const uint32_t total = range.y - range.x;
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
             uint32_t id = kInvalid;
             if (k < range.y) id = sorted_ids[k];
             FwdEntry e;
+            uint32_t strips = 0xFu;
             e.feat_id.w = __uint_as_float(id);
             if (id != kInvalid) {
                 const float4 a = density12[3 * (size_t)id + 0];
@@ -105,8 +112,10 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                 e.feat_id.x = fmaxf(feat[3 * (size_t)id + 0], 0.0f);
                 e.feat_id.y = fmaxf(feat[3 * (size_t)id + 1], 0.0f);
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
+                strips = strip_mask(s_planes, v, c, a, r, s);
             }
             stage[tid] = e;
+            s_mask[tid] = strips;
             if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
         }
         __syncthreads();
@@ -117,7 +126,6 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
         auto entry = [&](const float4& cs, const float4& c0, const float4& c1, const float4& c2, const uint32_t j)
                          __attribute__((always_inline)) {
             if (alive) {
-                consumed = base + j + 1;
                 float o0 = cs.x, o1 = cs.y, o2 = cs.z;
                 if (!centred) {
                     o0 += c0.x * ray.ex + c0.y * ray.ey + c0.z * ray.ez;
@@ -150,34 +158,53 @@ __global__ __launch_bounds__(kBlock) void k_render(ViewParams v, RenderConsts c,
                                 cb += fid.z * w;
                                 nhits++;
                             }
-                            if (T < c.min_transmittance) alive = false;
+                            if (T < c.min_transmittance) {
+                                alive = false;
+                                consumed = base + j + 1;  // list position at which this ray terminated
+                            }
                         }
                     }
                 }
             }
         };
-        // software pipeline, unrolled by two (two alternating register sets, no per-iteration moves): the parameters of
-        // entry j+1 are fetched from LDS while entry j is evaluated
+        // The wave first compacts the chunk to the entries whose cut-off ellipsoid can reach its 16x4 strip (ballot prefix,
+        // indices into a wave-private LDS list), then walks that list.  Software pipeline, unrolled by two (two alternating
+        // register sets, no per-iteration moves): the parameters of the next listed entry are fetched from LDS while the
+        // current one is evaluated.
         {
-            float4 a0 = stage[0].mu_sigma, a1 = stage[0].m0, a2 = stage[0].m1, a3 = stage[0].m2;
-            float4 b0, b1, b2, b3;
-            uint32_t j = 0;
-            while (j < cnt) {
-                if (__ballot(alive) == 0ull) break;  // wave-uniform
-                {
-                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
-                    b0 = stage[jn].mu_sigma; b1 = stage[jn].m0; b2 = stage[jn].m1; b3 = stage[jn].m2;
-                }
-                entry(a0, a1, a2, a3, j);
-                if (++j >= cnt) break;
-                if (__ballot(alive) == 0ull) break;
-                {
-                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
-                    a0 = stage[jn].mu_sigma; a1 = stage[jn].m0; a2 = stage[jn].m1; a3 = stage[jn].m2;
-                }
-                entry(b0, b1, b2, b3, j);
-                ++j;
+            uint16_t* list = s_list[tid >> 6];
+            const uint32_t lane = tid & 63u;
+            uint32_t nw = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < kBlock / 64; ++r) {
+                const uint32_t e = r * 64u + lane;
+                const bool keep = (e < cnt) && ((s_mask[e] & wave_bit) != 0u);
+                const unsigned long long bal = __ballot(keep);
+                if (keep) list[nw + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)e;
+                nw += (uint32_t)__popcll(bal);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t ja = list[0], jb = list[1];  // list positions i and i+1 (garbage beyond nw is never evaluated)
+            float4 a0 = stage[ja].mu_sigma, a1 = stage[ja].m0, a2 = stage[ja].m1, a3 = stage[ja].m2;
+            float4 b0, b1, b2, b3;
+            uint32_t i = 0;
+            while (i < nw) {
+                if (__ballot(alive) == 0ull) break;  // wave-uniform
+                b0 = stage[jb].mu_sigma; b1 = stage[jb].m0; b2 = stage[jb].m1; b3 = stage[jb].m2;
+                const uint32_t jc = list[min(i + 2, (uint32_t)kBlock - 1)];
+                entry(a0, a1, a2, a3, ja);
+                if (++i >= nw) break;
+                if (__ballot(alive) == 0ull) break;
+                a0 = stage[jc].mu_sigma; a1 = stage[jc].m0; a2 = stage[jc].m1; a3 = stage[jc].m2;
+                const uint32_t jd = list[min(i + 2, (uint32_t)kBlock - 1)];
+                entry(b0, b1, b2, b3, jb);
+                ++i;
+                ja = jc;
+                jb = jd;
+            }
+            if (alive) consumed = base + cnt;  // walked the whole chunk (skipped entries included) and is still alive
         }
         if (cnt < min((uint32_t)kBlock, total - base)) alive = false;  // list ended at a padding entry
     }
@@ -315,6 +342,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
     __shared__ FwdEntry stage[kBlock];
     __shared__ float acc[kBlock * W];
     __shared__ uint32_t s_deepest, s_first_invalid;
+    __shared__ uint32_t s_mask[kBlock];              // see k_render
+    __shared__ uint16_t s_list[kBlock / 64][kBlock];  // see k_render
+    __shared__ StripPlanes s_planes;
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // deepest tiles are dispatched first
     const uint32_t tid = threadIdx.x;
@@ -330,6 +360,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
         s_first_invalid = kBlock;
     }
     const bool centred = __syncthreads_and(ray.centred ? 1 : 0) != 0;  // block-uniform
+    build_strip_planes(s_planes, ray, inside, centred, tid);
+    const uint32_t wave_bit = 1u << (tid >> 6);
 #pragma unroll
     for (int k = 0; k < W; ++k) acc[k * kBlock + tid] = 0.0f;
 
@@ -366,6 +398,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
             uint32_t id = kInvalid;
             if (k < range.y) id = sorted_ids[k];
             FwdEntry e;
+            uint32_t strips = 0xFu;
             e.feat_id.w = __uint_as_float(id);
             if (id != kInvalid) {
                 const float4 a = density12[3 * (size_t)id + 0];
@@ -383,8 +416,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
                 e.feat_id.x = fmaxf(feat[3 * (size_t)id + 0], 0.0f);
                 e.feat_id.y = fmaxf(feat[3 * (size_t)id + 1], 0.0f);
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
+                strips = strip_mask(s_planes, v, c, a, r, sc);
             }
             stage[tid] = e;
+            s_mask[tid] = strips;
             if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
         }
         __syncthreads();
@@ -394,7 +429,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
         // one list entry for this wave's 64 pixels
         auto entry = [&](const float4& ms, const float4& m0, const float4& m1, const float4& m2, const uint32_t j)
                          __attribute__((always_inline)) {
-            if (alive) consumed = base + j + 1;
             float o0 = ms.x, o1 = ms.y, o2 = ms.z;
             if (!centred) {
                 o0 += m0.x * rex + m0.y * rey + m0.z * rez;
@@ -487,7 +521,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
             }
             g[9] = h0; g[10] = h1; g[11] = h2;
             T = Tn;  // unchanged for lanes that did not hit
-            if (hit && (T < c.min_transmittance)) alive = false;
+            if (hit && (T < c.min_transmittance)) {
+                alive = false;
+                consumed = base + j + 1;  // list position at which this ray terminated
+            }
 
             const float r = wave_transpose_reduce16(g, lane);
             if ((lane & 12u) == 0u) atomicAdd(&acc[j * W + my_slot], r);  // 16 lanes, 16 distinct addresses
@@ -500,28 +537,41 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
                 }
             }
         };
-        // software pipeline, unrolled by two so the prefetched parameters alternate between two register sets (no
-        // per-iteration register moves): entry j+1 is fetched from LDS while entry j is evaluated
+        // as in k_render: the wave compacts the chunk to the entries that can reach its strip, then walks that list with the
+        // two-register-set software pipeline
         {
-            float4 a0 = stage[0].mu_sigma, a1 = stage[0].m0, a2 = stage[0].m1, a3 = stage[0].m2;
-            float4 b0, b1, b2, b3;
-            uint32_t j = 0;
-            while (j < cnt) {
-                if (__ballot(alive) == 0ull) break;
-                {
-                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
-                    b0 = stage[jn].mu_sigma; b1 = stage[jn].m0; b2 = stage[jn].m1; b3 = stage[jn].m2;
-                }
-                entry(a0, a1, a2, a3, j);
-                if (++j >= cnt) break;
-                if (__ballot(alive) == 0ull) break;
-                {
-                    const uint32_t jn = min(j + 1, (uint32_t)kBlock - 1);
-                    a0 = stage[jn].mu_sigma; a1 = stage[jn].m0; a2 = stage[jn].m1; a3 = stage[jn].m2;
-                }
-                entry(b0, b1, b2, b3, j);
-                ++j;
+            uint16_t* list = s_list[tid >> 6];
+            uint32_t nw = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < kBlock / 64; ++r) {
+                const uint32_t e = r * 64u + lane;
+                const bool keep = (e < cnt) && ((s_mask[e] & wave_bit) != 0u);
+                const unsigned long long bal = __ballot(keep);
+                if (keep) list[nw + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)e;
+                nw += (uint32_t)__popcll(bal);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t ja = list[0], jb = list[1];
+            float4 a0 = stage[ja].mu_sigma, a1 = stage[ja].m0, a2 = stage[ja].m1, a3 = stage[ja].m2;
+            float4 b0, b1, b2, b3;
+            uint32_t i = 0;
+            while (i < nw) {
+                if (__ballot(alive) == 0ull) break;
+                b0 = stage[jb].mu_sigma; b1 = stage[jb].m0; b2 = stage[jb].m1; b3 = stage[jb].m2;
+                const uint32_t jc = list[min(i + 2, (uint32_t)kBlock - 1)];
+                entry(a0, a1, a2, a3, ja);
+                if (++i >= nw) break;
+                if (__ballot(alive) == 0ull) break;
+                a0 = stage[jc].mu_sigma; a1 = stage[jc].m0; a2 = stage[jc].m1; a3 = stage[jc].m2;
+                const uint32_t jd = list[min(i + 2, (uint32_t)kBlock - 1)];
+                entry(b0, b1, b2, b3, jb);
+                ++i;
+                ja = jc;
+                jb = jd;
+            }
+            if (alive) consumed = base + cnt;  // walked the whole chunk (skipped entries included) and is still alive
         }
 
         if (cnt < cnt_all) alive = false;  // list ended at a padding entry

@@ -85,6 +85,114 @@ struct FwdEntry {      // 80 bytes, 16-byte aligned: five ds_read_b128 broadcast
 };
 
 
+// ---- strip culling ---------------------------------------------------------------------------------
+// A wave owns a 16x4-pixel strip of the tile.  Tile lists are built per 16x16 tile, so a particle whose footprint covers
+// only part of the tile's height is listed for all four waves although some of them cannot hit it (42 % of the tested
+// (wave, entry) pairs of the bench frame have no hit lane).  Each wave therefore encloses the directions of its rays in a
+// double wedge between two planes through the sensor position, and the lane that stages an entry tests the entry's cut-off
+// ellipsoid {x : |M (x - mu)|^2 <= D} against the four wedges once; D is the largest d2 at which a hit is still possible
+// (response and alpha thresholds).  The test is exact for the wedge and conservative for the rays inside it: an entry is
+// skipped by a wave only if NO line through the sensor position with a direction in the wedge comes within D of it.
+//   wedge:      directions d with tau0 <= (n0.d)/(c.d) <= tau1   (c: the tile's central direction, n0: its image-down
+//               direction orthogonal to c, tau0/tau1: min/max over the wave's rays, widened by a relative 1e-5)
+//   planes:     n(tau) = n0 - tau c      (n(tau).d has the sign of tau_d - tau for c.d > 0)
+//   ellipsoid entirely outside  <=>  both plane distances delta_k = n_k.(mu - sensor) exceed the support half-width
+//               h_k = sqrt(D) |diag(s) R n_k| with the same sign  (lines extend both ways, hence the double wedge).
+// Rays that do not start at the sensor position, ragged tiles whose reference pixels fall outside the image and tiles whose
+// rays spread too widely around their central direction switch the test off for the whole tile (all masks 0xF).
+struct StripPlanes {
+    float n[4][2][3];
+    uint32_t usable;
+    float ref[3][3];  // scratch: rays of the top-middle, bottom-middle and centre pixel
+    uint32_t ref_ok;
+};
+
+// Called by all 256 threads of the tile (contains barriers).
+__device__ __forceinline__ void build_strip_planes(StripPlanes& sp, const RayState& ray, bool inside, bool centred, uint32_t tid) {
+    if (tid == 0) sp.ref_ok = 1u;
+    __syncthreads();
+    const int slot = tid == 8 ? 0 : (tid == 248 ? 1 : (tid == 136 ? 2 : -1));
+    if (slot >= 0) {
+        sp.ref[slot][0] = ray.dx; sp.ref[slot][1] = ray.dy; sp.ref[slot][2] = ray.dz;
+        if (!inside) sp.ref_ok = 0u;
+    }
+    __syncthreads();
+    bool ok = centred && (sp.ref_ok != 0u);
+    float c0 = 0.f, c1 = 0.f, c2 = 1.f, n0 = 0.f, n1 = 1.f, n2 = 0.f;
+    {
+        const float* a = sp.ref[0]; const float* b = sp.ref[1]; const float* m = sp.ref[2];
+        const float la = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], lb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+        const float lm = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+        ok = ok && (la > 0.f) && (lb > 0.f) && (lm > 0.f) && (la < 1e30f) && (lb < 1e30f) && (lm < 1e30f);
+        if (ok) {
+            const float ia = 1.0f / sqrtf(la), ib = 1.0f / sqrtf(lb), im = 1.0f / sqrtf(lm);
+            c0 = m[0] * im; c1 = m[1] * im; c2 = m[2] * im;
+            float d0 = b[0] * ib - a[0] * ia, d1 = b[1] * ib - a[1] * ia, d2 = b[2] * ib - a[2] * ia;
+            const float dc = d0 * c0 + d1 * c1 + d2 * c2;
+            d0 -= dc * c0; d1 -= dc * c1; d2 -= dc * c2;
+            const float ld = d0 * d0 + d1 * d1 + d2 * d2;
+            ok = ld > 1e-12f;
+            if (ok) {
+                const float id = 1.0f / sqrtf(ld);
+                n0 = d0 * id; n1 = d1 * id; n2 = d2 * id;
+            }
+        }
+    }
+    // this lane's elevation tangent inside the wedge parametrisation
+    float tau_lo = 3.0e38f, tau_hi = -3.0e38f;
+    bool lane_ok = true;
+    if (inside) {
+        const float cd = c0 * ray.dx + c1 * ray.dy + c2 * ray.dz;
+        const float nd = n0 * ray.dx + n1 * ray.dy + n2 * ray.dz;
+        const float l2 = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+        lane_ok = (l2 > 0.f) && (l2 < 1e30f) && (cd * cd > 0.01f * l2) && (cd > 0.f);  // within ~84 degrees of the central direction
+        const float tau = nd / cd;
+        if (lane_ok) { tau_lo = tau; tau_hi = tau; }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        tau_lo = fminf(tau_lo, __shfl_xor(tau_lo, m));
+        tau_hi = fmaxf(tau_hi, __shfl_xor(tau_hi, m));
+    }
+    const bool all_ok = __syncthreads_and((ok && lane_ok) ? 1 : 0) != 0;
+    if ((tid & 63u) == 0u) {
+        const uint32_t w = tid >> 6;
+        const float mag = 1.0f + fmaxf(fabsf(tau_lo), fabsf(tau_hi));
+        const float t0 = tau_lo - 1e-5f * mag, t1 = tau_hi + 1e-5f * mag;
+        sp.n[w][0][0] = n0 - t0 * c0; sp.n[w][0][1] = n1 - t0 * c1; sp.n[w][0][2] = n2 - t0 * c2;
+        sp.n[w][1][0] = n0 - t1 * c0; sp.n[w][1][1] = n1 - t1 * c1; sp.n[w][1][2] = n2 - t1 * c2;
+    }
+    if (tid == 0) sp.usable = all_ok ? 1u : 0u;
+    __syncthreads();
+}
+
+// bit w set <=> wave w has to evaluate the entry.  a = (mean, density), r = rows of rotationT, s = scale
+__device__ __forceinline__ uint32_t strip_mask(const StripPlanes& sp, const ViewParams& v, const RenderConsts& c, const float4& a,
+                                               const float (&r)[3][3], const float4& s) {
+    if (sp.usable == 0u) return 0xFu;
+    const float ratio = a.w / c.alpha_threshold;  // alpha = resp * density > threshold  <=>  d2 < 2 ln(density / threshold)
+    if (!(ratio > 1.0f)) return 0u;               // cannot be hit at all (K1 culls these already)
+    const float D = fminf(c.max_d2, 2.0f * __logf(ratio)) * 1.001f + 1e-3f;
+    const float m0 = a.x - v.s2w.t[0], m1 = a.y - v.s2w.t[1], m2 = a.z - v.s2w.t[2];
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        bool above = true, below = true;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float n0 = sp.n[w][k][0], n1 = sp.n[w][k][1], n2 = sp.n[w][k][2];
+            const float delta = n0 * m0 + n1 * m1 + n2 * m2;
+            const float t0 = s.x * (r[0][0] * n0 + r[0][1] * n1 + r[0][2] * n2);
+            const float t1 = s.y * (r[1][0] * n0 + r[1][1] * n1 + r[1][2] * n2);
+            const float t2 = s.z * (r[2][0] * n0 + r[2][1] * n1 + r[2][2] * n2);
+            const bool clear = delta * delta > D * (t0 * t0 + t1 * t1 + t2 * t2);  // |delta| > h
+            above = above && clear && (delta > 0.0f);
+            below = below && clear && (delta < 0.0f);
+        }
+        if (!(above || below)) mask |= 1u << w;
+    }
+    return mask;
+}
+
 // stage one list entry (lane-private id) into its LDS slot in the canonical-space form
 __device__ __forceinline__ FwdEntry make_entry(const ViewParams& v, const float4* __restrict__ density12,
                                                const float* __restrict__ feat, uint32_t id) {
