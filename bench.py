@@ -37,6 +37,11 @@ WORKLOADS = {
     "bicycle_like_6M_1237x822": ("scene_outdoor_like", dict(n=6_000_000, seed=2), 1237, 822, 1040.0, 4.5, 12.0, 5.0),
     "lego_like_300k_800x800": ("scene_lego_like", dict(n=300_000, seed=1), 800, 800, 1111.1, 4.0, 25.0, 1.3),
     "c1_1k_128x128": ("scene_c1", dict(n=1000, seed=0), 128, 128, 128.0, 4.0, 0.0, 1.0),
+    # BASELINE configs[3]: ScanNet++-DSLR-like OpenCV fisheye (zero radial coefficients, as its loader sets them), camera
+    # inside the scene; fx is the fisheye focal length (equidistant model): ~150 degrees across the 1752-pixel width
+    "scannetpp_like_fisheye_300k_1752x1168": ("scene_lego_like", dict(n=300_000, seed=3), 1752, 1168, 660.0, 0.6, 10.0, 1.3),
+    # BASELINE configs[4]: MipNeRF360-garden-like, one view per GPU
+    "garden_like_5M_1297x840": ("scene_outdoor_like", dict(n=5_000_000, seed=4), 1297, 840, 1090.0, 4.2, 15.0, 5.0),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -61,8 +66,8 @@ def algorithmic_bytes(st, kernel, end_bit):
     }[kernel]
 
 
-def make_views(cams, n_views, W, H, fx, radius, elev):
-    ro, rd = cams.pinhole_rays(W, H, fx, fx)
+def make_views(cams, n_views, W, H, fx, radius, elev, fisheye=False):
+    ro, rd = cams.fisheye_rays(W, H, fx, fx) if fisheye else cams.pinhole_rays(W, H, fx, fx)
     views = []
     for i in range(n_views):
         c2w = cams.orbit_c2w(radius, 360.0 * i / n_views + 7.0, elev)
@@ -100,6 +105,46 @@ def cpu_baseline(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degree, budget_s=3
             "sample": f"one full {W}x{H} frame of the {d12.shape[0]}-Gaussian workload, render forward+backward only (no loss, no "
                       f"optimiser), C restatement oracle/gut_oracle.c with OpenMP on {threads} threads: {how}; "
                       f"M = {fwd['M']} intersections"}
+
+
+def cpu_baseline_per_ray_torch(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degree, budget_s=8.0):
+    """Pure-PyTorch per-ray composite (oracle/per_ray_torch.py), forward + autograd backward, fp32, on the rays of a
+    centred crop; the Gaussian set is culled with the UT projection rule to the ones whose 2-D extent touches the
+    crop (otherwise brute force over all 6 M).  The crop doubles until ~budget_s of CPU work is reached."""
+    prt = importlib.import_module("oracle.per_ray_torch")
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(threads)
+    tq = pose_mod.sensor_pose_from_c2w(c2w).T_world_sensors[0]
+    cam = dict(model="pinhole", principal_point=[W / 2, H / 2], focal_length=[fx, fx])
+    ro, rd = cams_mod.pinhole_rays(W, H, fx, fx)
+    params = {k: torch.tensor(v) for k, v in scene.items()}
+    pr = prt.project(cam, tq, W, H, params, dtype=torch.float32)
+    crop, best = 4, None
+    while True:
+        x0, y0 = W // 2 - crop // 2, H // 2 - crop // 2
+        c, e = pr["center"], pr["extent"]
+        inb = pr["valid"] & (c[:, 0] + e[:, 0] >= x0) & (c[:, 0] - e[:, 0] <= x0 + crop) & \
+            (c[:, 1] + e[:, 1] >= y0) & (c[:, 1] - e[:, 1] <= y0 + crop)
+        idx = torch.nonzero(inb).squeeze(1)
+        sub = {k: v[idx].clone().requires_grad_(True) for k, v in params.items()}
+        ys, xs = torch.meshgrid(torch.arange(y0, y0 + crop), torch.arange(x0, x0 + crop), indexing="ij")
+        pix = (ys * W + xs).reshape(-1)
+        t1 = time.time()
+        rgba, dist, hits = prt.render_per_ray(cam, tq, W, H, sub, ro, rd, sh_degree=sh_degree, dtype=torch.float32,
+                                              pixel_subset=pix, pix_chunk=1024, gauss_chunk=1024)
+        rgba.sum().backward()
+        dt = time.time() - t1
+        best = (crop, dt, int(idx.numel()))
+        if dt * 3.5 > budget_s or crop * 2 > min(W, H):
+            break
+        crop *= 2
+    crop, dt, ng = best
+    rays = crop * crop
+    img_s = 1.0 / (dt * (W * H) / rays)
+    return {"value": img_s, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"render fwd+bwd only (no loss/Adam) on a {crop}x{crop} centre crop = {rays} of {W * H} rays vs the "
+                      f"{ng} UT-culled Gaussians touching it; pure-PyTorch fp32 per-ray composite + autograd took {dt:.2f} s; "
+                      f"value is extrapolated to the full image"}
 
 
 def main():
@@ -171,9 +216,11 @@ def main():
         stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
 
     n_views = max(8, world)
-    ro, rd, c2ws = make_views(cams, n_views, W, H, fx, radius, elev)
+    fisheye = "fisheye" in args.workload
+    ro, rd, c2ws = make_views(cams, n_views, W, H, fx, radius, elev, fisheye)
     ro_t, rd_t = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
-    K = cams.pinhole_intrinsics_dict(W, H, fx, fx)
+    K = cams.fisheye_intrinsics_dict(W, H, fx, fx) if fisheye else cams.pinhole_intrinsics_dict(W, H, fx, fx)
+    kkey = "intrinsics_OpenCVFisheyeCameraModelParameters" if fisheye else "intrinsics_OpenCVPinholeCameraModelParameters"
     g = torch.Generator(device="cpu").manual_seed(100)
     yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
     gt = torch.stack([0.5 + 0.4 * torch.sin(6.0 * xx), 0.5 + 0.4 * torch.cos(5.0 * yy), 0.5 * (xx + yy)], -1)
@@ -184,8 +231,7 @@ def main():
         # the 4x4 pose stays on the host (the tracer needs it there to fill the camera struct; a device tensor would
         # cost a blocking read-back per step, as in the reference's tracer.py:353-356)
         pose = torch.as_tensor(c2ws[v])[None] if args.host_pose else torch.as_tensor(c2ws[v], device=dev)[None]
-        return gut.Batch(rays_ori=ro_t, rays_dir=rd_t, T_to_world=pose, rgb_gt=gt,
-                         intrinsics_OpenCVPinholeCameraModelParameters=K)
+        return gut.Batch(rays_ori=ro_t, rays_dir=rd_t, T_to_world=pose, rgb_gt=gt, **{kkey: K})
 
     def barrier():
         if dist is not None:
@@ -270,7 +316,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
+                if fisheye:
+                    raise RuntimeError("the CPU baselines are wired for the pinhole workloads")
                 out["cpu_baseline"] = cpu_baseline(scene, cams, pose_mod, W, H, fx, c2ws[0], sh_degree)
+                # north_star's wording: a pure-PyTorch per-ray composite on the host cores, same run (second, smaller sample)
+                out["cpu_baseline_per_ray_torch"] = cpu_baseline_per_ray_torch(scene, cams, pose_mod, W, H, fx, c2ws[0], sh_degree)
             except Exception as e:  # the baseline is reported, never a gate
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
