@@ -15,6 +15,7 @@ GUT_NUM_KERNEL_TIMERS = 9
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
 BWD_SKIP_EPILOGUE = 4
+OPT_LAZY_TILE_ORDER = 1
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer")
 
 SHUTTER_GLOBAL = 4
@@ -22,7 +23,7 @@ CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
 
 BUF = dict(tiles_count=0, tiles_offset=1, proj_pos=2, conic_opacity=3, extent=4, depth=5, feat=6,
            unsorted_keys=7, unsorted_ids=8, sorted_keys=9, sorted_ids=10, tile_ranges=11, grad_scratch=12,
-           tile_traversed_fwd=13, tile_traversed_bwd=14)
+           tile_traversed_fwd=13, tile_traversed_bwd=14, ordered_ids=15)
 
 
 class GutCamera(C.Structure):
@@ -59,7 +60,7 @@ class GutStats(C.Structure):
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
-           "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd",
+           "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
            "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
 
 _lib = None
@@ -108,6 +109,7 @@ def load():
     fptr = C.POINTER(C.c_float)
     lib.gut_optimize_after_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float, u32,
                                            vp, vp]
+    lib.gut_set_option.argtypes = [vp, i32, i32]
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
                                      C.c_float, C.c_float, C.c_float, u32, vp, vp, u32]

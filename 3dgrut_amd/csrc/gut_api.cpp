@@ -120,6 +120,12 @@ struct gut_context {
     DevBuf tiles_count, tiles_offset, proj_pos, conic_opacity, extent, depth, feat, grad16, scan_temp;
     // per-M scratch
     DevBuf keys_unsorted, keys_sorted, ids_unsorted, ids_sorted, sort_temp;
+    // lazy per-tile depth order (unsorted variant): keys_sorted / ids_sorted are grouped by tile only, the forward compositor
+    // writes the ids it consumed, in final order, to ids_ordered; the fully sorted lists exist only on debug request
+    DevBuf ids_ordered, dbg_keys_sorted, dbg_ids_sorted;
+    bool lazy_enabled = true;      // gut_set_option(GUT_OPT_LAZY_TILE_ORDER)
+    bool lazy_order = false;       // this forward used the lazy order
+    bool dbg_sorted_valid = false;
     // per-T
     DevBuf ranges, trav_fwd, trav_bwd, tile_order;  // per-tile traversal depths (statistics)
     DevBuf counters;
@@ -325,7 +331,8 @@ void gut_destroy(gut_handle h) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
-                      &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters};
+                      &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters, &h->ids_ordered,
+                      &h->dbg_keys_sorted, &h->dbg_ids_sorted};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
@@ -418,18 +425,33 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     }
     mark(2);
     const int end_bit = 32 + (int)bit_width_u32((uint32_t)tiles);
+    // the k-buffer variant walks whole lists: it keeps the full sort
+    // ... and frames whose tile lists are so long on average that re-scanning them per 512 ordered entries cannot pay
+    const bool lazy = h->lazy_enabled && h->cfg.k_buffer_size == 0 && m != 0 && (uint64_t)m < (uint64_t)tiles * 16384ull;
+    h->lazy_order = lazy;
+    h->dbg_sorted_valid = false;
     if (m) {
         HIP_TRY(h->keys_unsorted.ensure(sizeof(uint64_t) * (size_t)m));
         HIP_TRY(h->keys_sorted.ensure(sizeof(uint64_t) * (size_t)m));
         HIP_TRY(h->ids_unsorted.ensure(sizeof(uint32_t) * (size_t)m));
         HIP_TRY(h->ids_sorted.ensure(sizeof(uint32_t) * (size_t)m));
-        HIP_TRY(h->sort_temp.ensure(gut::sort_temp_bytes(m, end_bit)));
         gut::launch_expand(s, v, h->consts, n, h->tiles_offset.as<uint32_t>(), h->proj_pos.as<float>(),
                            h->conic_opacity.as<float>(), h->extent.as<float>(), h->depth.as<float>(),
                            h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>());
         mark(3);
-        HIP_TRY(gut::run_sort(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(), h->keys_sorted.as<uint64_t>(),
-                              h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, end_bit));
+        if (lazy) {
+            HIP_TRY(h->sort_temp.ensure(gut::sort_tiles_temp_bytes(m, end_bit)));
+            HIP_TRY(h->ids_ordered.ensure(sizeof(uint32_t) * (size_t)m));
+            // unwritten positions read as padding ids (end of list) in the backward
+            HIP_TRY(hipMemsetAsync(h->ids_ordered.p, 0xFF, sizeof(uint32_t) * (size_t)m, s));
+            HIP_TRY(gut::run_sort_tiles(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(),
+                                        h->keys_sorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m,
+                                        end_bit));
+        } else {
+            HIP_TRY(h->sort_temp.ensure(gut::sort_temp_bytes(m, end_bit)));
+            HIP_TRY(gut::run_sort(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(), h->keys_sorted.as<uint64_t>(),
+                                  h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, end_bit));
+        }
         mark(4);
         gut::launch_tile_ranges(s, m, h->keys_sorted.as<uint64_t>(), h->ranges.as<uint32_t>());
     } else {
@@ -447,7 +469,8 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     } else {
         gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
                            h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, d_ray_radiance_density, d_ray_hit_distance,
-                           d_ray_hit_count, h->trav_fwd.as<uint32_t>());
+                           d_ray_hit_count, h->trav_fwd.as<uint32_t>(), lazy ? h->keys_sorted.as<uint64_t>() : nullptr,
+                           lazy ? h->ids_ordered.as<uint32_t>() : nullptr);
     }
     mark(6);
     HIP_TRY(hipGetLastError());
@@ -545,7 +568,8 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
     } else if (h->m) {
         gut::launch_tile_order(s, (uint32_t)h->tiles, h->trav_fwd.as<uint32_t>(), h->tile_order.as<uint32_t>());
         gut::launch_render_bwd(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
-                               h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_ray_radiance_density,
+                               h->ranges.as<uint32_t>(), (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(),
+                               d_ray_radiance_density,
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
                                h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>());
     }
@@ -597,6 +621,15 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     }
     h->have_backward = false;  // the gradient rows are consumed
     return 0;
+}
+
+int gut_set_option(gut_handle h, int32_t option, int32_t value) {
+    if (!h) return fail("gut_set_option: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    switch (option) {
+    case GUT_OPT_LAZY_TILE_ORDER: h->lazy_enabled = value != 0; return 0;
+    default: return fail("gut_set_option: unknown option %d", option);
+    }
 }
 
 int gut_collect_times(gut_handle h, float* forward_render_ms, float* backward_render_ms) {
@@ -701,8 +734,30 @@ int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes) {
     case GUT_BUF_FEATURES: *d_ptr = h->feat.p; *bytes = 12 * n; break;
     case GUT_BUF_UNSORTED_KEYS: *d_ptr = h->keys_unsorted.p; *bytes = 8 * m; break;
     case GUT_BUF_UNSORTED_IDS: *d_ptr = h->ids_unsorted.p; *bytes = 4 * m; break;
-    case GUT_BUF_SORTED_KEYS: *d_ptr = h->keys_sorted.p; *bytes = 8 * m; break;
-    case GUT_BUF_SORTED_IDS: *d_ptr = h->ids_sorted.p; *bytes = 4 * m; break;
+    case GUT_BUF_SORTED_KEYS:
+    case GUT_BUF_SORTED_IDS:
+        if (h->lazy_order) {  // the product path never needs the fully sorted lists: build them for the caller
+            if (!h->dbg_sorted_valid && m) {
+                HIP_TRY(hipSetDevice(h->device));
+                HIP_TRY(h->dbg_keys_sorted.ensure(8 * m));
+                HIP_TRY(h->dbg_ids_sorted.ensure(4 * m));
+                DevBuf tmp;
+                HIP_TRY(tmp.ensure(gut::sort_temp_bytes((uint32_t)m, h->end_bit)));
+                hipError_t e = gut::run_sort(h->fwd_stream, tmp.p, tmp.cap, h->keys_unsorted.as<uint64_t>(),
+                                             h->dbg_keys_sorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>(),
+                                             h->dbg_ids_sorted.as<uint32_t>(), (uint32_t)m, h->end_bit);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->fwd_stream);
+                tmp.release();
+                HIP_TRY(e);
+                h->dbg_sorted_valid = true;
+            }
+            if (which == GUT_BUF_SORTED_KEYS) { *d_ptr = h->dbg_keys_sorted.p; *bytes = 8 * m; }
+            else { *d_ptr = h->dbg_ids_sorted.p; *bytes = 4 * m; }
+        } else if (which == GUT_BUF_SORTED_KEYS) { *d_ptr = h->keys_sorted.p; *bytes = 8 * m; }
+        else { *d_ptr = h->ids_sorted.p; *bytes = 4 * m; }
+        break;
+    case GUT_BUF_ORDERED_IDS:
+        *d_ptr = h->lazy_order ? h->ids_ordered.p : h->ids_sorted.p; *bytes = 4 * m; break;
     case GUT_BUF_TILE_RANGES: *d_ptr = h->ranges.p; *bytes = 8 * t; break;
     case GUT_BUF_GRAD_SCRATCH:
         if (!h->have_backward) return fail("gut_debug_buffer: no backward yet");

@@ -69,7 +69,7 @@ void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_d
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                    const uint32_t* sorted_ids, uint32_t num_intersections, float* rgba, float* dist, float* hits,
-                   uint32_t* tile_traversed);
+                   uint32_t* tile_traversed, const uint64_t* tile_keys /* lazy order only */, uint32_t* ordered_ids /* NULL = list is fully sorted */);
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
@@ -99,5 +99,8 @@ hipError_t run_scan(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t
 size_t sort_temp_bytes(uint32_t m, int end_bit);
 hipError_t run_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                     const uint32_t* vals_in, uint32_t* vals_out, uint32_t m, int end_bit);
+size_t sort_tiles_temp_bytes(uint32_t m, int end_bit);
+hipError_t run_sort_tiles(hipStream_t s, void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                          const uint32_t* vals_in, uint32_t* vals_out, uint32_t m, int end_bit);
 
 }  // namespace gut

@@ -51,17 +51,22 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 // K6 forward
 // ---------------------------------------------------------------------------------------------------
 // (5 waves per SIMD: at the 103 VGPRs the compiler takes otherwise the kernel runs 7 % slower, at 6 it spills)
+// kLazy: sorted_ids / tile_keys are only grouped by tile; the kernel orders each chunk itself (lazy_select) and records the
+// ids it consumed in ordered_ids for the backward.
+template <bool kLazy>
 __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts c, const float4* __restrict__ density12,
-                                                  const float* __restrict__ feat, const float* __restrict__ ray_ori,
-                                                  const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
-                                                  const uint32_t* __restrict__ sorted_ids, uint32_t num_intersections,
-                                                  float4* __restrict__ rgba, float* __restrict__ dist,
-                                                  float* __restrict__ hits, uint32_t* __restrict__ tile_traversed) {
+                                                     const float* __restrict__ feat, const float* __restrict__ ray_ori,
+                                                     const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
+                                                     const uint32_t* __restrict__ sorted_ids, uint32_t num_intersections,
+                                                     float4* __restrict__ rgba, float* __restrict__ dist,
+                                                     float* __restrict__ hits, uint32_t* __restrict__ tile_traversed,
+                                                     const uint2* __restrict__ tile_keys, uint32_t* __restrict__ ordered_ids) {
     __shared__ FwdEntry stage[kBlock];
     __shared__ uint32_t s_deepest, s_first_invalid;
     __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (16x4 strips) can hit it at all
     __shared__ uint16_t s_list[kBlock / 64][kBlock];  // per wave: the staged entries it has to evaluate (index), in list order
     __shared__ StripPlanes s_planes;
+    __shared__ LazyOrder s_lazy;
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -86,13 +91,32 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     bool alive = ray.valid;
     float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dsum = 0.f;
     uint32_t nhits = 0, consumed = 0;
+    bool have_lo = false;           // kLazy: the last list entry ordered so far (block-uniform)
+    uint32_t lo_d = 0, lo_p = 0, batch_n = 0, batch_used = 0;
 
     for (uint32_t base = 0; base < total; base += kBlock) {
         if (!__syncthreads_or(alive ? 1 : 0)) break;  // whole tile terminated (gutKBufferRenderer.cuh:234-236)
         {
             const uint32_t k = range.x + base + tid;
             uint32_t id = kInvalid;
-            if (k < range.y) id = sorted_ids[k];
+            if (kLazy) {
+                if (batch_used == batch_n) {  // block-uniform: order the next kLazyBatch entries of the tile
+                    batch_n = min(kLazyBatch, total - base);
+                    lazy_select(s_lazy, tile_keys + range.x, total, batch_n, have_lo, lo_d, lo_p, tid);
+                    have_lo = true;
+                    lo_d = s_lazy.sel_depth[batch_n - 1];
+                    lo_p = s_lazy.sel_pos[batch_n - 1];
+                    batch_used = 0;
+                }
+                const uint32_t take = min((uint32_t)kBlock, batch_n - batch_used);
+                if (tid < take) {
+                    id = sorted_ids[range.x + s_lazy.sel_pos[batch_used + tid]];
+                    ordered_ids[k] = id;
+                }
+                batch_used += take;
+            } else if (k < range.y) {
+                id = sorted_ids[k];
+            }
             FwdEntry e;
             uint32_t strips = 0xFu;
             e.feat_id.w = __uint_as_float(id);
@@ -649,12 +673,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
 // ---------------------------------------------------------------------------------------------------
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                   uint32_t num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed) {
+                   uint32_t num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed,
+                   const uint64_t* tile_keys, uint32_t* ordered_ids) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
-    hipLaunchKernelGGL(k_render, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12), feat,
+    auto kern = ordered_ids != nullptr ? k_render<true> : k_render<false>;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12), feat,
                        ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, num_intersections,
-                       reinterpret_cast<float4*>(rgba), dist, hits, tile_traversed);
+                       reinterpret_cast<float4*>(rgba), dist, hits, tile_traversed, reinterpret_cast<const uint2*>(tile_keys),
+                       ordered_ids);
 }
 
 // Launch order for the backward: tiles by decreasing forward traversal depth (the backward walks exactly as deep),

@@ -193,6 +193,139 @@ __device__ __forceinline__ uint32_t strip_mask(const StripPlanes& sp, const View
     return mask;
 }
 
+// ---- lazy per-tile depth order ------------------------------------------------------------------------
+// Whole-tile termination leaves most of a tile's list untouched (bench frame: 1.28 M of 9.36 M entries are ever staged),
+// so the global sort only groups the (tile | depth, id) pairs by TILE (the two high radix passes; stable, so every tile's
+// entries stay in particle-id order) and the forward compositor orders each tile on demand: before it stages a chunk it
+// selects the next <= 256 entries in (depth bits, list position) order — list position == particle-id order, i.e. exactly
+// the order the full stable sort on (tile | depth) produces — writes their ids to the ordered-id list (the backward and
+// the tests read that) and stages them.  Selection = 4 x 8-bit radix select on the depth bits among the entries behind the
+// last one taken, one ordered gather pass, one 256-element bitonic sort in LDS.
+constexpr uint32_t kLazyBatch = 512;  // entries ordered per selection: two 256-entry chunks (power of two for the bitonic sort)
+
+struct LazyOrder {
+    uint32_t hist[256];
+    uint32_t sel_depth[kLazyBatch];
+    uint32_t sel_pos[kLazyBatch];
+    uint32_t wave_cnt[2][4][4];  // [less | equal][unrolled position][wave]
+    uint32_t bin, need;
+};
+
+// keys: the tile's slice of the tile-grouped (tile << 32 | depth bits) keys; total = its length; want = min(kLazyBatch,
+// entries not yet taken); (have_lo, lo_d, lo_p) = the last entry taken so far.  Called by all 256 threads (contains
+// barriers).  On return sel_pos[t] / sel_depth[t], t < want, hold the next `want` entries in final order.
+// Every pass walks the list four 256-entry rows at a time with the four loads issued back to back.  (Not inlined: inlined,
+// its register needs made the compiler spill the compositing loop's state, 2.4x slower; a variant that kept the first 4 .. 16
+// rows of depths in registers across the passes was measured slower as well, for the same reason.)
+
+__device__ __noinline__ void lazy_select(LazyOrder& S, const uint2* __restrict__ keys, uint32_t total, uint32_t want, bool have_lo,
+                                         uint32_t lo_d, uint32_t lo_p, uint32_t tid) {
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    auto behind_lo = [&](uint32_t d, uint32_t p) { return !have_lo || d > lo_d || (d == lo_d && p > lo_p); };
+    // 1. depth of the want-th smallest remaining entry, digit by digit
+    uint32_t prefix = 0, need = want;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        S.hist[tid] = 0u;
+        __syncthreads();
+        const uint32_t hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t p0 = tid; p0 < total; p0 += 4 * kBlock) {
+            uint32_t d[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) d[u] = (p0 + u * kBlock) < total ? keys[p0 + u * kBlock].x : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t p = p0 + u * kBlock;
+                if (p < total && behind_lo(d[u], p) && ((d[u] & hi_mask) == (prefix & hi_mask)))
+                    atomicAdd(&S.hist[(d[u] >> shift) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {  // first bin at which the running count reaches `need`
+            const uint32_t h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2], h3 = S.hist[4 * lane + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t incl = mine;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if ((int)lane >= o) incl += up;
+            }
+            const unsigned long long reach = __ballot(incl >= need);
+            const uint32_t first = (uint32_t)__ffsll((long long)reach) - 1u;  // always found: the candidates number >= need
+            if (lane == first) {
+                uint32_t c = incl - mine, b = 4 * lane;
+                if (c + h0 < need) { c += h0; ++b; if (c + h1 < need) { c += h1; ++b; if (c + h2 < need) { c += h2; ++b; } } }
+                S.bin = b;
+                S.need = need - c;
+            }
+        }
+        __syncthreads();
+        prefix |= S.bin << shift;
+        need = S.need;
+    }
+    const uint32_t dstar = prefix;       // its depth bits; `need` entries with exactly this depth are taken, in list order
+    const uint32_t n_less = want - need;  // entries with a smaller depth: all taken
+    // 2. ordered gather (list order = row, then wave, then lane)
+    uint32_t got_lt = 0, got_eq = 0;
+    for (uint32_t base = 0; base < total; base += 4 * kBlock) {
+        if (got_lt == n_less && got_eq >= need) break;  // block-uniform
+        uint32_t d[4];
+        unsigned long long b_lt[4], b_eq[4];
+        bool lt[4], eq[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) d[u] = (base + u * kBlock + tid) < total ? keys[base + u * kBlock + tid].x : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t p = base + u * kBlock + tid;
+            const bool cand = (p < total) && behind_lo(d[u], p);
+            lt[u] = cand && d[u] < dstar;
+            eq[u] = cand && d[u] == dstar;
+            b_lt[u] = __ballot(lt[u]);
+            b_eq[u] = __ballot(eq[u]);
+            if (lane == 0) {
+                S.wave_cnt[0][u][wave] = (uint32_t)__popcll(b_lt[u]);
+                S.wave_cnt[1][u][wave] = (uint32_t)__popcll(b_eq[u]);
+            }
+        }
+        __syncthreads();
+        const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t run_lt = got_lt, run_eq = got_eq;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            uint32_t my_lt = run_lt, my_eq = run_eq;
+#pragma unroll
+            for (uint32_t w = 0; w < kBlock / 64; ++w) {
+                if (w < wave) { my_lt += S.wave_cnt[0][u][w]; my_eq += S.wave_cnt[1][u][w]; }
+                run_lt += S.wave_cnt[0][u][w];
+                run_eq += S.wave_cnt[1][u][w];
+            }
+            my_lt += (uint32_t)__popcll(b_lt[u] & below);
+            my_eq += (uint32_t)__popcll(b_eq[u] & below);
+            const uint32_t p = base + u * kBlock + tid;
+            if (lt[u]) { S.sel_depth[my_lt] = d[u]; S.sel_pos[my_lt] = p; }
+            if (eq[u] && my_eq < need) { S.sel_depth[n_less + my_eq] = d[u]; S.sel_pos[n_less + my_eq] = p; }
+        }
+        got_lt = run_lt;
+        got_eq = run_eq;
+        __syncthreads();
+    }
+    for (uint32_t t = tid; t < kLazyBatch; t += kBlock)
+        if (t >= want) { S.sel_depth[t] = 0xFFFFFFFFu; S.sel_pos[t] = 0xFFFFFFFFu; }
+    __syncthreads();
+    // 3. bitonic sort of the kLazyBatch slots by (depth, position); every thread owns one compare-exchange per stage
+    for (uint32_t k = 2; k <= kLazyBatch; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < kLazyBatch / 2; t += kBlock) {
+                const uint32_t e = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), o = e | j;
+                const uint32_t d0 = S.sel_depth[e], p0 = S.sel_pos[e], d1 = S.sel_depth[o], p1 = S.sel_pos[o];
+                const bool gt = d0 > d1 || (d0 == d1 && p0 > p1);
+                if (gt == ((e & k) == 0u)) {
+                    S.sel_depth[e] = d1; S.sel_pos[e] = p1;
+                    S.sel_depth[o] = d0; S.sel_pos[o] = p0;
+                }
+            }
+            __syncthreads();
+        }
+}
+
 // stage one list entry (lane-private id) into its LDS slot in the canonical-space form
 __device__ __forceinline__ FwdEntry make_entry(const ViewParams& v, const float4* __restrict__ density12,
                                                const float* __restrict__ feat, uint32_t id) {

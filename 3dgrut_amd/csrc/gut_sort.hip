@@ -43,4 +43,18 @@ hipError_t run_sort(hipStream_t s, void* temp, size_t temp_bytes, const uint64_t
                                      (unsigned int)end_bit, s);
 }
 
+// Tile-only grouping for the lazy per-tile depth order (gut_render_common.h: LazyOrder): the same keys, sorted on the tile
+// bits [32, end_bit) alone — two radix passes instead of five; stable, so each tile keeps its entries in particle order.
+size_t sort_tiles_temp_bytes(uint32_t m, int end_bit) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, (size_t)m, 32u, (unsigned int)end_bit, (hipStream_t)0);
+    return bytes;
+}
+
+hipError_t run_sort_tiles(hipStream_t s, void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                          const uint32_t* vals_in, uint32_t* vals_out, uint32_t m, int end_bit) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)m, 32u, (unsigned int)end_bit, s);
+}
+
 }  // namespace gut

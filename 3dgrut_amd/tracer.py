@@ -266,6 +266,10 @@ class SplatRaster:
         return dict(self._timings)
 
     # ---- extensions used by tests / bench (not part of the reference surface) ----
+    def set_lazy_tile_order(self, on=True):
+        """Tile-only radix grouping + per-tile lazy depth order in the forward compositor (default on; gut_hip.h)."""
+        _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_LAZY_TILE_ORDER, 1 if on else 0), "set_option")
+
     def stats(self):
         s = _capi.GutStats()
         _capi.check(self._lib.gut_get_stats(self._handle, C.byref(s)), "stats")
@@ -287,7 +291,7 @@ class SplatRaster:
         ptr, nbytes = C.c_void_p(), C.c_size_t()
         _capi.check(self._lib.gut_debug_buffer(self._handle, _capi.BUF[name], C.byref(ptr), C.byref(nbytes)), "debug_buffer")
         dt = {"tiles_count": torch.int32, "tiles_offset": torch.int32, "unsorted_ids": torch.int32,
-              "sorted_ids": torch.int32, "tile_ranges": torch.int32, "tile_traversed_fwd": torch.int32,
+              "sorted_ids": torch.int32, "ordered_ids": torch.int32, "tile_ranges": torch.int32, "tile_traversed_fwd": torch.int32,
               "tile_traversed_bwd": torch.int32, "unsorted_keys": torch.int64,
               "sorted_keys": torch.int64}.get(name, torch.float32)
         n = nbytes.value // (8 if dt == torch.int64 else 4)

@@ -50,7 +50,7 @@ def algorithmic_bytes(st, kernel, end_bit):
     """SURVEY.md §8d byte model, per kernel launch."""
     N, V, M, T, P = (st[k] for k in ("num_particles", "num_visible", "num_intersections", "num_tiles", "num_pixels"))
     Ef, Eb = st["traversed_fwd"], st["traversed_bwd"]
-    b = math.ceil(end_bit / 9)  # onesweep passes: 9-bit digits (csrc/gut_sort.hip)
+    b = math.ceil((end_bit - 32) / 8)  # lazy tile order (default): onesweep passes over the tile bits only (csrc/gut_sort.hip)
     return {
         "project": (48 + 44) * N + 204 * V,
         "scan": 8 * N,
@@ -165,6 +165,7 @@ def main():
                          "(exercises the N>1 call sequence on a one-GPU box; the number is NOT a bench line)")
     ap.add_argument("--device-pose", dest="host_pose", action="store_false",
                     help="hand the 4x4 camera pose over as a GPU tensor (reference layout; costs one blocking read-back per step)")
+    ap.add_argument("--full-sort", action="store_true", help="switch GUT_OPT_LAZY_TILE_ORDER off (full 44-bit radix sort)")
     ap.add_argument("--selective-adam", action="store_true", help="visibility-masked Adam (reference SelectiveAdam)")
     args = ap.parse_args()
 
@@ -206,6 +207,8 @@ def main():
     scene = getattr(scenes, fn)(**kw)  # same seed on every rank -> identical replicas
     sh_degree = 3
     tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
+    if args.full_sort:
+        tracer.tracer_wrapper.set_lazy_tile_order(False)
     if args.trainer == "native":
         native_mod = importlib.import_module("3dgrut_amd.native")
         model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree)

@@ -102,12 +102,14 @@ enum {
     GUT_BUF_FEATURES = 6,      /* f32 [N,3] precomputed view-dependent RGB (unclamped) */
     GUT_BUF_UNSORTED_KEYS = 7, /* u64 [M] */
     GUT_BUF_UNSORTED_IDS = 8,  /* u32 [M] */
-    GUT_BUF_SORTED_KEYS = 9,   /* u64 [M] */
+    GUT_BUF_SORTED_KEYS = 9,   /* u64 [M]  (SORTED_*: the reference's fully sorted lists; built on request, see ORDERED_IDS) */
     GUT_BUF_SORTED_IDS = 10,   /* u32 [M] */
     GUT_BUF_TILE_RANGES = 11,  /* u32 [T,2] */
     GUT_BUF_GRAD_SCRATCH = 12, /* f32 [N,16] per-Gaussian gradient rows of the last trace_bwd */
     GUT_BUF_TILE_TRAVERSED_FWD = 13, /* u32 [T] list entries each tile walked before all its rays terminated */
-    GUT_BUF_TILE_TRAVERSED_BWD = 14  /* u32 [T] same, last trace_bwd */
+    GUT_BUF_TILE_TRAVERSED_BWD = 14, /* u32 [T] same, last trace_bwd */
+    GUT_BUF_ORDERED_IDS = 15   /* u32 [M] what the compositors actually walked: per tile, the ids in final order for the chunks the
+                                  forward staged (0xFFFFFFFF beyond); equals SORTED_IDS on those positions */
 };
 
 /* fills *cfg with the reference defaults (configs/render/3dgut.yaml + 3dgrt.yaml) */
@@ -174,6 +176,15 @@ int gut_get_stats(gut_handle h, GutStats* out);
 int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes);
 /* copies a debug buffer into caller-owned DEVICE memory of at least `bytes` bytes (stream-ordered, then synchronised) */
 int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
+
+/* Runtime options of a handle (take effect at the next gut_trace).
+ * GUT_OPT_LAZY_TILE_ORDER (default 1; unsorted variant only): group the (tile | depth) keys by tile only (2 of the 5 radix
+ * passes) and let the forward compositor put each tile's entries in depth order 512 at a time, as far as the tile is
+ * actually walked (whole-tile termination leaves most of every list untouched: 86 % on the bench frame).  Images, traversal
+ * depths and gradients are identical to the fully sorted path; GUT_BUF_ORDERED_IDS shows what was walked, GUT_BUF_SORTED_*
+ * still return the reference's full lists (built on request).  0 restores the full radix sort. */
+#define GUT_OPT_LAZY_TILE_ORDER 1
+int gut_set_option(gut_handle h, int32_t option, int32_t value);
 
 /* per-kernel hipEvent timings of the last trace / trace_bwd (ms), for bench.py's roofline block.
  * Order: project, scan, expand, sort, ranges, render, render_bwd, project_bwd, optimizer (gut_optimize_after_bwd; -1 when

@@ -141,6 +141,10 @@ def test_full_size_frame_against_the_oracle(frame):
     for key in ("unsorted_keys", "sorted_keys"):
         assert np.array_equal(b[key].cpu().numpy().view(np.uint64), ref[key]), key
     assert np.array_equal(b["tile_ranges"].cpu().numpy().view(np.uint32).reshape(-1, 2), ref["tile_ranges"])
+    # the lazily ordered lists the compositors walked are a prefix of the reference's sorted lists in every tile
+    ordered = frame["raster"].debug_buffer("ordered_ids").cpu().numpy().view(np.uint32)
+    written = ordered != 0xFFFFFFFF
+    assert written.sum() >= frame["stats"]["traversed_fwd"] and np.array_equal(ordered[written], ref["sorted_ids"][written])
     for key in ("proj_pos", "conic_opacity", "extent", "depth", "feat"):
         got = frame["raster"].debug_buffer(key).cpu().numpy().view(np.uint32)
         exp = np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)

@@ -53,9 +53,11 @@ def _oracle_inputs(sc, sh_degree=3):
         return model, d12, model.get_features().cpu().numpy()
 
 
-def _run_gpu(sc, view, sh_degree, rgba_grad=None, dist_grad=None, timings=False, model=None):
+def _run_gpu(sc, view, sh_degree, rgba_grad=None, dist_grad=None, timings=False, model=None, lazy=None):
     model = model if model is not None else gut_model(sc, sh_degree)
     tr = gut.Tracer({"render": {"enable_kernel_timings": timings}})
+    if lazy is not None:
+        tr.tracer_wrapper.set_lazy_tile_order(lazy)
     batch = to_batch(view, DEV)
     out = tr.render(model, batch, train=True, frame_id=0)
     res = dict(out=out, tracer=tr, model=model)
@@ -94,6 +96,21 @@ def _activated_grads(model, dens_g, sph_g):
     return {k: v.grad.numpy() for k, v in raw.items()}
 
 
+def _check_ordered_ids(raster, ref):
+    """What the compositors actually walked (the product path orders every tile lazily, chunk by chunk) must be the prefix
+    of the reference's fully sorted list: identical ids on every position the forward staged, padding ids elsewhere, and
+    every tile staged exactly the 256-entry chunks its traversal depth needs."""
+    ordered = raster.debug_buffer("ordered_ids").cpu().numpy().view(np.uint32)
+    written = ordered != 0xFFFFFFFF
+    assert np.array_equal(ordered[written], ref["sorted_ids"][written])
+    trav = raster.debug_buffer("tile_traversed_fwd").cpu().numpy().view(np.uint32)
+    for t, (b, e) in enumerate(ref["tile_ranges"]):
+        if e > b:
+            staged = int(written[b:e].sum())
+            assert written[b:b + staged].all()                              # a prefix
+            assert staged >= min(int(trav[t]), e - b) and (staged % 256 == 0 or staged == e - b)
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_forward_buffers_and_image(name):
     mk, kind, W, H, (eye, tgt), kw = CASES[name]
@@ -117,6 +134,7 @@ def test_forward_buffers_and_image(name):
         assert np.array_equal(got, ref[key]), key
     got = raster.debug_buffer("tile_ranges").cpu().numpy().view(np.uint32).reshape(-1, 2)
     assert np.array_equal(got, ref["tile_ranges"])
+    _check_ordered_ids(raster, ref)
     # projection floats: bit-exact under the shared numerics contract
     for key, refkey in (("proj_pos", "proj_pos"), ("conic_opacity", "conic_opacity"), ("extent", "extent"), ("depth", "depth"),
                         ("feat", "feat")):
@@ -378,3 +396,26 @@ def test_unusable_rays_do_not_poison_gradients():
         g = getattr(res["model"], k).grad.cpu().numpy()
         assert np.isfinite(g).all(), k
         assert rel_l2(g, e) <= 2e-3, f"{k}: rel L2 {rel_l2(g, e)}"
+
+
+@pytest.mark.parametrize("name", ["c1_pinhole_128", "fisheye_144x96", "dense_big_splats", "inside_cloud"])
+def test_lazy_tile_order_is_equivalent(name):
+    """GUT_OPT_LAZY_TILE_ORDER (the default) against the full radix sort: same image,
+    same traversal depths, same gradients; the walked lists are prefixes of the reference's fully sorted lists."""
+    mk, kind, W, H, (eye, tgt), kw = CASES[name]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    rgba_grad = np.random.default_rng(3).normal(size=(H, W, 4)).astype(np.float32)
+    model, d12, sph = _oracle_inputs(sc, 3)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    a = _run_gpu(sc, view, 3, rgba_grad=rgba_grad, model=model, lazy=False)
+    ga = {k: getattr(model, k).grad.clone() for k in ("positions", "rotation", "scale", "density", "features_albedo")}
+    model.zero_grad(set_to_none=True)
+    b = _run_gpu(sc, view, 3, rgba_grad=rgba_grad, model=model, lazy=True)
+    assert torch.equal(a["out"]["pred_rgb"], b["out"]["pred_rgb"]) and torch.equal(a["out"]["pred_dist"], b["out"]["pred_dist"])
+    ra, rb = a["tracer"].tracer_wrapper, b["tracer"].tracer_wrapper
+    assert torch.equal(ra.debug_buffer("tile_traversed_fwd"), rb.debug_buffer("tile_traversed_fwd"))
+    assert np.array_equal(rb.debug_buffer("sorted_ids").cpu().numpy().view(np.uint32), ref["sorted_ids"])
+    _check_ordered_ids(rb, ref)
+    for k, g in ga.items():
+        assert rel_l2(getattr(model, k).grad.cpu().numpy(), g.cpu().numpy()) <= 1e-5, k
