@@ -84,3 +84,24 @@ def pack_density(scene):
     n = scene["positions"].shape[0]
     return np.concatenate([scene["positions"], scene["density"], scene["rotation"], scene["scale"],
                            np.zeros((n, 1), np.float32)], axis=1).astype(np.float32)
+
+
+def morton_order(positions, bits=10):
+    """Permutation that sorts points along a 3-D Morton (Z-order) curve over their bounding box (bits per axis <= 10)."""
+    p = np.asarray(positions, np.float64)
+    lo, hi = p.min(0), p.max(0)
+    q = np.clip(((p - lo) / np.maximum(hi - lo, 1e-12) * ((1 << bits) - 1)).astype(np.uint64), 0, (1 << bits) - 1)
+
+    def spread(v):
+        v = (v | (v << 16)) & np.uint64(0x030000FF)
+        v = (v | (v << 8)) & np.uint64(0x0300F00F)
+        v = (v | (v << 4)) & np.uint64(0x030C30C3)
+        v = (v | (v << 2)) & np.uint64(0x09249249)
+        return v
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    return np.argsort(code, kind="stable")
+
+
+def reorder(scene, perm):
+    return {k: v[perm] for k, v in scene.items()}

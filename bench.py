@@ -165,6 +165,9 @@ def main():
                          "(exercises the N>1 call sequence on a one-GPU box; the number is NOT a bench line)")
     ap.add_argument("--device-pose", dest="host_pose", action="store_false",
                     help="hand the 4x4 camera pose over as a GPU tensor (reference layout; costs one blocking read-back per step)")
+    ap.add_argument("--morton-order", action="store_true",
+                    help="store the Gaussians in Morton (Z-curve) order instead of the scene's random order (NOT the bench line: "
+                         "shows what a spatially coherent parameter layout is worth)")
     ap.add_argument("--full-sort", action="store_true", help="switch GUT_OPT_LAZY_TILE_ORDER off (full 44-bit radix sort)")
     ap.add_argument("--selective-adam", action="store_true", help="visibility-masked Adam (reference SelectiveAdam)")
     args = ap.parse_args()
@@ -205,6 +208,8 @@ def main():
     if args.num_gaussians:
         kw["n"] = args.num_gaussians
     scene = getattr(scenes, fn)(**kw)  # same seed on every rank -> identical replicas
+    if args.morton_order:
+        scene = scenes.reorder(scene, scenes.morton_order(scene["positions"]))
     sh_degree = 3
     tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
     if args.full_sort:

@@ -176,3 +176,15 @@ def test_fisheye_rays_invert_the_forward_polynomial():
     x, y = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5, indexing="xy")
     want = np.sqrt(((x - W / 2) / f) ** 2 + ((y - H / 2) / f) ** 2)
     assert np.abs(delta - want).max() <= 2e-4      # three Newton steps (the reference's setting) from the linear guess
+
+
+def test_morton_order_is_a_locality_preserving_permutation():
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-1, 1, size=(4096, 3))
+    perm = scenes.morton_order(pts)
+    assert sorted(perm.tolist()) == list(range(4096))
+    d_sorted = np.linalg.norm(np.diff(pts[perm], axis=0), axis=1).mean()
+    d_random = np.linalg.norm(np.diff(pts, axis=0), axis=1).mean()
+    assert d_sorted < 0.25 * d_random
+    sc = scenes.reorder(scenes.scene_c1(100, 0), scenes.morton_order(scenes.scene_c1(100, 0)["positions"]))
+    assert sc["features"].shape == (100, 48)
