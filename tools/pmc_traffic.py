@@ -71,6 +71,6 @@ if adam:
              f"{plain['roofline']['mean_launch_ms']:.3f} ms plain) agree.\n")
 L.append("History of this round's bench line on the same workload: 62 -> 86 -> 98 -> 153 -> 171 -> 186 (deepest-first tile order) -> 212 "
          "(compositor instruction diet) -> 227 (fused loss, no per-step pose read-back) -> 236 (9-bit sort digits, activation fused into "
-         "Adam) -> 245 (backward epilogue folded into the optimiser kernel) -> 233 .. 251 with strip culling -> 245 .. 257 images/s with the lazy per-tile depth order, depending on the box: "
+         "Adam) -> 245 (backward epilogue folded into the optimiser kernel) -> 233 .. 251 with strip culling -> 245 .. 260 images/s with the lazy per-tile depth order and a 6-bit-digit tile grouping, depending on the box: "
          "the optimiser kernel ran between 1.54 and 1.85 ms (6.0 .. 5.0 TB/s) on boxes whose plain device copy measured 5.4 .. 4.9 TB/s.\n")
 open(os.path.join(dst, "README.md"), "w").write("\n".join(L))
