@@ -25,6 +25,11 @@
 
 namespace gut {
 
+// stage[j] for a list index held in a VGPR: 24-bit multiply (full rate) instead of the quarter-rate 32-bit one
+__device__ __forceinline__ const FwdEntry& stage_at(const FwdEntry* stage, uint32_t j) {
+    return *reinterpret_cast<const FwdEntry*>(reinterpret_cast<const char*>(stage) + __umul24(j, (uint32_t)sizeof(FwdEntry)));
+}
+
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ float dpp_add(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, kRowMask, 0xF, true);
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                             dsum += hit_t * w;
                             T *= (1.0f - alpha);
                             if (w > 0.0f) {
-                                const float4 fid = stage[j].feat_id;
+                                const float4 fid = stage_at(stage, j).feat_id;
                                 cr += fid.x * w;
                                 cg += fid.y * w;
                                 cb += fid.z * w;
@@ -211,17 +216,17 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             uint32_t ja = list[0], jb = list[1];  // list positions i and i+1 (garbage beyond nw is never evaluated)
-            float4 a0 = stage[ja].mu_sigma, a1 = stage[ja].m0, a2 = stage[ja].m1, a3 = stage[ja].m2;
+            float4 a0 = stage_at(stage, ja).mu_sigma, a1 = stage_at(stage, ja).m0, a2 = stage_at(stage, ja).m1, a3 = stage_at(stage, ja).m2;
             float4 b0, b1, b2, b3;
             uint32_t i = 0;
             while (i < nw) {
                 if (__ballot(alive) == 0ull) break;  // wave-uniform
-                b0 = stage[jb].mu_sigma; b1 = stage[jb].m0; b2 = stage[jb].m1; b3 = stage[jb].m2;
+                b0 = stage_at(stage, jb).mu_sigma; b1 = stage_at(stage, jb).m0; b2 = stage_at(stage, jb).m1; b3 = stage_at(stage, jb).m2;
                 const uint32_t jc = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(a0, a1, a2, a3, ja);
                 if (++i >= nw) break;
                 if (__ballot(alive) == 0ull) break;
-                a0 = stage[jc].mu_sigma; a1 = stage[jc].m0; a2 = stage[jc].m1; a3 = stage[jc].m2;
+                a0 = stage_at(stage, jc).mu_sigma; a1 = stage_at(stage, jc).m0; a2 = stage_at(stage, jc).m1; a3 = stage_at(stage, jc).m2;
                 const uint32_t jd = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(b0, b1, b2, b3, jb);
                 ++i;
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
             const float rm = hit ? resp : 0.0f;
             float g[16];
             float gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;  // direct scale terms (kDistGrad only)
-            const float4 fid = stage[j].feat_id;
+            const float4 fid = stage_at(stage, j).feat_id;
             const float w = am * T;
             const float Tn = (1.0f - am) * T;
             const float t = (u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (u.o)/|u|^2
@@ -578,17 +583,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             uint32_t ja = list[0], jb = list[1];
-            float4 a0 = stage[ja].mu_sigma, a1 = stage[ja].m0, a2 = stage[ja].m1, a3 = stage[ja].m2;
+            float4 a0 = stage_at(stage, ja).mu_sigma, a1 = stage_at(stage, ja).m0, a2 = stage_at(stage, ja).m1, a3 = stage_at(stage, ja).m2;
             float4 b0, b1, b2, b3;
             uint32_t i = 0;
             while (i < nw) {
                 if (__ballot(alive) == 0ull) break;
-                b0 = stage[jb].mu_sigma; b1 = stage[jb].m0; b2 = stage[jb].m1; b3 = stage[jb].m2;
+                b0 = stage_at(stage, jb).mu_sigma; b1 = stage_at(stage, jb).m0; b2 = stage_at(stage, jb).m1; b3 = stage_at(stage, jb).m2;
                 const uint32_t jc = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(a0, a1, a2, a3, ja);
                 if (++i >= nw) break;
                 if (__ballot(alive) == 0ull) break;
-                a0 = stage[jc].mu_sigma; a1 = stage[jc].m0; a2 = stage[jc].m1; a3 = stage[jc].m2;
+                a0 = stage_at(stage, jc).mu_sigma; a1 = stage_at(stage, jc).m0; a2 = stage_at(stage, jc).m1; a3 = stage_at(stage, jc).m2;
                 const uint32_t jd = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(b0, b1, b2, b3, jb);
                 ++i;
