@@ -18,8 +18,14 @@
 // scheme, and each wave-instruction of the flush covers 4 rows x 16 contiguous floats.  Waves in
 // which no lane hit the entry skip the reduction altogether (wave-uniform branch on __ballot).
 //
+// Three further pieces live in gut_render_common.h: the per-wave strip culling (double-wedge test of each staged entry's
+// cut-off ellipsoid; every wave walks its own compacted entry list), the lazy per-tile depth order (the global sort only
+// groups by tile; K6 orders 512 entries at a time as far as the tile is walked and hands the ordered ids to K7), and the
+// staging form of an entry.  The backward launches its tiles deepest-first (k_tile_order).
+//
 // Colour/gradient buffers are compared with the oracle by tolerance, so this file is compiled with FMA
-// contraction on and uses the hardware exp/rcp/rsq approximations.
+// contraction on and uses the hardware exp/rcp/rsq approximations.  Build flags that matter: -fno-slp-vectorize (the
+// SLP vectoriser's v_pk_* packing is a net loss here) and the launch bounds of k_render (5 waves per SIMD).
 #include "gut_internal.h"
 #include "gut_render_common.h"
 
