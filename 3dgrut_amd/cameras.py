@@ -6,11 +6,22 @@ threedgrut/datasets/camera_models.py:156-235 (OpenCV fisheye, zero radial coeffi
 ScanNet++ loader uses, dataset_scannetpp.py:43-45; max_angle rule dataset_colmap.py:167-172).
 Camera convention: "right-down-front" (+x right, +y down, +z forward), protocols.py:79-86.
 """
+import enum
 import math
 
 import numpy as np
 
-SHUTTER_GLOBAL = 4  # sensors/cameraModels.h:34-40
+
+@enum.unique
+class ShutterType(enum.IntEnum):
+    """The DATASET-side shutter enum (threedgrut/datasets/camera_models.py:29-36: `IntEnum` with `auto()`, i.e. 1..5).
+    This is what the reference's `*CameraModelParameters.to_dict()` puts under "shutter_type"; the tracer maps it by
+    name to the plugin enum 0..4 (threedgut_tracer/tracer.py:365-371)."""
+    ROLLING_TOP_TO_BOTTOM = 1
+    ROLLING_LEFT_TO_RIGHT = 2
+    ROLLING_BOTTOM_TO_TOP = 3
+    ROLLING_RIGHT_TO_LEFT = 4
+    GLOBAL = 5
 
 
 def look_at_c2w(eye, target, up=(0.0, -1.0, 0.0)):
@@ -42,7 +53,7 @@ def pinhole_rays(W, H, fx, fy):
 
 def pinhole_intrinsics_dict(W, H, fx, fy, cx=None, cy=None):
     return dict(
-        resolution=np.array([W, H], np.int64), shutter_type=SHUTTER_GLOBAL,
+        resolution=np.array([W, H], np.int64), shutter_type=ShutterType.GLOBAL,
         principal_point=np.array([W / 2 if cx is None else cx, H / 2 if cy is None else cy], np.float32),
         focal_length=np.array([fx, fy], np.float32), radial_coeffs=np.zeros(6, np.float32),
         tangential_coeffs=np.zeros(2, np.float32), thin_prism_coeffs=np.zeros(4, np.float32),
@@ -86,7 +97,7 @@ def fisheye_intrinsics_dict(W, H, fx, fy, cx=None, cy=None):
     cx = W / 2 if cx is None else cx
     cy = H / 2 if cy is None else cy
     return dict(
-        resolution=np.array([W, H], np.int64), shutter_type=SHUTTER_GLOBAL,
+        resolution=np.array([W, H], np.int64), shutter_type=ShutterType.GLOBAL,
         principal_point=np.array([cx, cy], np.float32), focal_length=np.array([fx, fy], np.float32),
         radial_coeffs=np.zeros(4, np.float32), max_angle=float(fisheye_max_angle(W, H, fx, fy, cx, cy)),
     )

@@ -66,6 +66,21 @@ struct DevBuf {
     T* as() const { return static_cast<T*>(p); }
 };
 
+// Every entry point runs on the handle's device and leaves the calling thread's current device as it found it
+// (a host application with several GPUs per process must not see its device change under it).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t set(int device) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { prev = -1; return e; }
+        if (prev == device) { prev = -1; return hipSuccess; }
+        return hipSetDevice(device);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     bool armed = false;
@@ -305,7 +320,8 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_index < 0 || device_index >= ndev) return fail("gut_create: device %d out of range (%d devices)", device_index, ndev);
-    HIP_TRY(hipSetDevice(device_index));
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(device_index));
     gut_context* h = new (std::nothrow) gut_context();
     if (!h) return fail("gut_create: out of host memory");
     h->device = device_index;
@@ -327,7 +343,8 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
 
 void gut_destroy(gut_handle h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dev_guard;
+    (void)dev_guard.set(h->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
@@ -359,7 +376,8 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
         return fail("gut_trace: null particle buffers with %u particles", num_particles);
     std::lock_guard<std::mutex> lock(h->mu);
     hipStream_t s = static_cast<hipStream_t>(stream_);
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
     gut::ViewParams v;
     if (build_view(camera, width, height, &v)) return 1;
     const uint32_t n = num_particles;
@@ -539,7 +557,8 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
         return fail("gut_trace_bwd: null pointer argument");
     if (num_particles && (!d_particle_density || (!(flags & GUT_BWD_SKIP_EPILOGUE) && (!d_particle_density_grad || !d_particle_radiance_grad))))
         return fail("gut_trace_bwd: null particle buffers");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
     gut::ViewParams v;
     if (build_view(camera, width, height, &v)) return 1;
     if (memcmp(&v, &h->view, sizeof(v)) != 0) return fail("gut_trace_bwd: camera differs from the cached forward");
@@ -608,7 +627,8 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     if (h->n == 0) return 0;
     if (!d_camera_position || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48)
         return fail("gut_optimize_after_bwd: null pointer argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
     const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[12] && h->kev[13];
     if (timing) (void)hipEventRecord(h->kev[12], s);
     gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, d_camera_position, h->grad16.as<float>(), h->tiles_count.as<uint32_t>(),
@@ -701,7 +721,8 @@ int gut_get_stats(gut_handle h, GutStats* out) {
     std::lock_guard<std::mutex> lock(h->mu);
     memset(out, 0, sizeof(*out));
     if (!h->have_forward) return fail("gut_get_stats: no forward yet");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(gut::Counters), h->fwd_stream));
     gut::launch_stats_reduce(h->fwd_stream, h->n, h->tiles_count.as<uint32_t>(), (uint32_t)h->tiles, h->trav_fwd.as<uint32_t>(),
                              h->trav_bwd.as<uint32_t>(), h->counters.as<gut::Counters>());
@@ -738,7 +759,8 @@ int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes) {
     case GUT_BUF_SORTED_IDS:
         if (h->lazy_order) {  // the product path never needs the fully sorted lists: build them for the caller
             if (!h->dbg_sorted_valid && m) {
-                HIP_TRY(hipSetDevice(h->device));
+                DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
                 HIP_TRY(h->dbg_keys_sorted.ensure(8 * m));
                 HIP_TRY(h->dbg_ids_sorted.ensure(4 * m));
                 DevBuf tmp;
@@ -778,7 +800,8 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes) {
     if (bytes < have) return fail("gut_debug_copy: destination holds %zu bytes, buffer has %zu", bytes, have);
     if (have == 0) return 0;
     std::lock_guard<std::mutex> lock(h->mu);
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
     HIP_TRY(hipMemcpyAsync(d_dst, src, have, hipMemcpyDeviceToDevice, h->fwd_stream));
     HIP_TRY(hipStreamSynchronize(h->fwd_stream));
     return 0;

@@ -83,7 +83,9 @@ def read_images_binary(path):
             f.seek(24 * n2d, os.SEEK_CUR)  # (x, y, point3D_id) per observation: not needed
             out.append(ColmapImage(vals[0], np.array(vals[1:5], np.float64), np.array(vals[5:8], np.float64), vals[8],
                                    name.decode("utf-8")))
-    return out
+    # sorted by image name, as the reference's readers return them (datasets/utils.py:500,565): the every-n-th
+    # train/test split indexes this order (pinned by tests/golden/host_golden.json)
+    return sorted(out, key=lambda im: im.name)
 
 
 def read_points3D_binary(path):
@@ -123,7 +125,7 @@ def read_images_text(path):
         t = head.split()
         out.append(ColmapImage(int(t[0]), np.array([float(x) for x in t[1:5]]), np.array([float(x) for x in t[5:8]]), int(t[8]),
                                " ".join(t[9:])))
-    return out
+    return sorted(out, key=lambda im: im.name)
 
 
 def _data_lines_keep_pairs(path):

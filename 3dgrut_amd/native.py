@@ -78,7 +78,7 @@ class NativeGaussianModel:
 class NativeTrainStep:
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
                  betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2,
-                 dp_chunks=4, dp_chunk_min_rows=1 << 20, fuse_epilogue=True):
+                 dp_chunks=4, dp_chunk_min_rows=1 << 20, fuse_epilogue=True, schedule=None):
         self.model = model
         self.tracer = tracer
         self.raster: SplatRaster = tracer.tracer_wrapper
@@ -96,6 +96,12 @@ class NativeTrainStep:
         lr48 = np.full(48, 0.000125, np.float32)  # specular
         lr48[0:3] = 0.0025                  # albedo
         self.lr12, self.lr48 = lr12, lr48
+        # schedule.TrainSchedule: exponentially decayed position rate + progressive SH degree (trainer.py:745-765).
+        # None keeps both constant (the steady-state regime the bench measures).
+        self.schedule = schedule
+        if schedule is not None:
+            self.lr12[0:3] = schedule.position_lr
+            model.n_active_features = schedule.n_active_features
         z = lambda c: torch.zeros((n, c), dtype=torch.float32, device=dev)
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
         self.fused = bool(fused_sh_adam)
@@ -264,9 +270,7 @@ class NativeTrainStep:
                                                0 if self.selective else self.step_id + 1, vmask, self.act)
                 self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
                 self._mark(evs)
-                if evs is not None:
-                    self._phase_events.append(evs)
-                self.step_id += 1
+                self._end_of_step(evs)
                 return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
             # this view's compact radiance gradient: directly view 0 of the gathered layout when there is nothing to gather
             local_mrgb = self.mrgb_local if exchange else self.mrgb[0][0]
@@ -319,10 +323,17 @@ class NativeTrainStep:
             self._adam(m.raw, self.g12, self.m12, self.v12, self.lr12, vmask)
             self._adam(m.features, self.g48, self.m48, self.v48, self.lr48, vmask)
         self._mark(evs)
+        self._end_of_step(evs)
+        return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
+
+    def _end_of_step(self, evs):
         if evs is not None:
             self._phase_events.append(evs)
+        if self.schedule is not None:   # scheduler_step(g) + SH-degree increase, after the optimiser (trainer.py:756-765)
+            lr, deg = self.schedule.after_optimizer_step(self.step_id)
+            self.lr12[0:3] = lr         # passed by value to the optimiser kernels of the next step
+            self.model.n_active_features = deg
         self.step_id += 1
-        return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
 
     def render(self, batch, train=False):
         return self.tracer.render(self.model, batch, train=train, frame_id=self.step_id)

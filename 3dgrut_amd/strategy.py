@@ -31,6 +31,19 @@ def _quat_to_rotmat(q):
         torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1)], 1)
 
 
+def multinomial_sample(weights, n, generator=None):
+    """`n` indices drawn with replacement, probability proportional to `weights` (flat, non-negative).
+    torch.multinomial refuses more than 2^24 categories; the reference falls back to numpy on the host there
+    (threedgrut/utils/misc.py:164-196).  Here larger inputs are sampled on the device by inverting the cumulative sum
+    (float64, one searchsorted), which draws from the same distribution without leaving the GPU."""
+    assert weights.dim() == 1, "multinomial_sample expects a flat tensor"
+    if weights.shape[0] <= 2 ** 24:
+        return torch.multinomial(weights, n, replacement=True, generator=generator)
+    cdf = torch.cumsum(weights.to(torch.float64), 0)
+    u = torch.rand(n, dtype=torch.float64, device=weights.device, generator=generator) * cdf[-1]
+    return torch.searchsorted(cdf, u, right=True).clamp_(max=weights.shape[0] - 1)
+
+
 class _StateOps:
     """Row surgery on (raw, features) + Adam moments of a NativeTrainStep."""
 
@@ -180,7 +193,7 @@ class MCMCStrategy:
         if valid_idx is None:
             valid_idx = torch.arange(dens.shape[0], device=dens.device)
         gen = torch.Generator(device=dens.device).manual_seed(self.seed * 1_000_003 + step)
-        sampled = valid_idx[torch.multinomial(dens[valid_idx], num, replacement=True, generator=gen)]
+        sampled = valid_idx[multinomial_sample(dens[valid_idx], num, gen)]
         ratios = (torch.bincount(sampled, minlength=dens.shape[0])[sampled] + 1).clamp_(min=1, max=self.n_max).int()
         new_d, new_s = self._relocation(dens[sampled].contiguous(), scales[sampled].contiguous(), ratios.contiguous())
         new_d = new_d.clamp(max=1.0 - torch.finfo(torch.float32).eps, min=self.opacity_threshold)

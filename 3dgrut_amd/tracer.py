@@ -21,18 +21,43 @@ import numpy as np
 import torch
 
 from . import _capi
+from .cameras import ShutterType as DatasetShutterType
 from .pose import SensorPose3D, sensor_pose_from_c2w
 
 
 # ----------------------------------------------------------------------------------------------------
 # native-module surface (lib3dgut_cc equivalent)
 # ----------------------------------------------------------------------------------------------------
-class ShutterType(enum.IntEnum):  # bindings.cpp:87-92
+class ShutterType(enum.IntEnum):  # the PLUGIN enum, bindings.cpp:87-92 / sensors/cameraModels.h:34-40
     ROLLING_TOP_TO_BOTTOM = 0
     ROLLING_LEFT_TO_RIGHT = 1
     ROLLING_BOTTOM_TO_TOP = 2
     ROLLING_RIGHT_TO_LEFT = 3
     GLOBAL = 4
+
+
+# dataset enum (1..5) -> plugin enum (0..4), by name: threedgut_tracer/tracer.py:365-371 (SHUTTER_TYPE_MAP)
+SHUTTER_TYPE_MAP = {d: ShutterType[d.name] for d in DatasetShutterType}
+
+
+def plugin_shutter_type(value):
+    """K["shutter_type"] of a dataset batch -> plugin ShutterType.  Accepts the dataset enum member, its int value
+    1..5 (IntEnum members hash like their ints, so the reference's dict lookup accepts both too) or the member name
+    (what a JSON round trip of `to_dict()` leaves behind).  Anything else raises KeyError like the reference's lookup."""
+    if isinstance(value, ShutterType):
+        raise KeyError(f"shutter_type {value!r} is already the plugin enum; a Batch carries the dataset enum (1..5)")
+    if isinstance(value, str):
+        name = value.split(".")[-1]
+        if name not in DatasetShutterType.__members__:
+            raise KeyError(f"unknown shutter_type {value!r}")
+        return ShutterType[name]
+    v = value.item() if hasattr(value, "item") else value
+    if isinstance(v, bool) or not isinstance(v, int):
+        raise KeyError(f"unknown shutter_type {value!r}")
+    try:
+        return SHUTTER_TYPE_MAP[DatasetShutterType(v)]
+    except ValueError:
+        raise KeyError(f"unknown shutter_type {value!r} (dataset enum is 1..5, camera_models.py:29-36)") from None
 
 
 class CameraModelParameters:
@@ -399,12 +424,12 @@ class Tracer:
                 thin_prism_coeffs=np.zeros((4,), dtype=np.float32)), poses
         if (K := getattr(gpu_batch, "intrinsics_OpenCVPinholeCameraModelParameters", None)) is not None:
             return fromOpenCVPinholeCameraModelParameters(
-                resolution=K["resolution"], shutter_type=ShutterType(int(K["shutter_type"])),
+                resolution=K["resolution"], shutter_type=plugin_shutter_type(K["shutter_type"]),
                 principal_point=K["principal_point"], focal_length=K["focal_length"], radial_coeffs=K["radial_coeffs"],
                 tangential_coeffs=K["tangential_coeffs"], thin_prism_coeffs=K["thin_prism_coeffs"]), poses
         if (K := getattr(gpu_batch, "intrinsics_OpenCVFisheyeCameraModelParameters", None)) is not None:
             return fromOpenCVFisheyeCameraModelParameters(
-                resolution=K["resolution"], shutter_type=ShutterType(int(K["shutter_type"])),
+                resolution=K["resolution"], shutter_type=plugin_shutter_type(K["shutter_type"]),
                 principal_point=K["principal_point"], focal_length=K["focal_length"], radial_coeffs=K["radial_coeffs"],
                 max_angle=K["max_angle"]), poses
         raise ValueError("Camera intrinsics unavailable or unsupported")

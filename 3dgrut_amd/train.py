@@ -57,7 +57,7 @@ def photometric_loss_torch(pred_rgb, gt_rgb, lambda_l1=0.8, lambda_ssim=0.2, win
 
 
 class TrainStep:
-    def __init__(self, model, tracer, scene_extent=1.0, world_size=1, fused_adam=True):
+    def __init__(self, model, tracer, scene_extent=1.0, world_size=1, fused_adam=True, schedule=None):
         self.model = model
         self.tracer = tracer
         self.world_size = world_size
@@ -67,6 +67,15 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(model.param_groups(scene_extent), **kw)
         self.window = _gauss_window(device=next(model.parameters()).device)
         self.step_id = 0
+        self.schedule = schedule   # schedule.TrainSchedule or None (constant rates, fixed SH degree)
+        if schedule is not None:
+            self._set_schedule_state(schedule.position_lr, schedule.n_active_features)
+
+    def _set_schedule_state(self, lr, deg):
+        for group in self.optimizer.param_groups:   # model.scheduler_step, model.py:540-545
+            if group["name"] == "positions":
+                group["lr"] = lr
+        self.model.n_active_features = deg
 
     def render(self, batch, train=True):
         return self.tracer.render(self.model, batch, train=train, frame_id=self.step_id)
@@ -79,6 +88,8 @@ class TrainStep:
             self.allreduce_gradients()
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
+        if self.schedule is not None:
+            self._set_schedule_state(*self.schedule.after_optimizer_step(self.step_id))
         self.step_id += 1
         return loss, out
 

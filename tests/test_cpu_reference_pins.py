@@ -1,0 +1,330 @@
+"""Host side of the boundary against fixtures produced by the REFERENCE's own Python (tests/golden/gen_host_golden.py,
+run in the build container; the fixtures are data, nothing of the reference travels).
+
+Pinned here: `_Autograd` packing / argument order / 12-slot backward, `create_camera_parameters` (dataset -> plugin shutter
+mapping, keyword arguments of fromOpenCV*, pose), `Tracer.render`'s output dict, pinhole and OpenCV-fisheye camera rays,
+fisheye max_angle rule, COLMAP readers (binary + text, ordering), scene extent, SH constants, the exponential
+position-LR schedule and the SH-degree step rule.  The device kernels stay "parity unpinned" (DESIGN.md §3).
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+gut = importlib.import_module("3dgrut_amd")
+tracer_mod = importlib.import_module("3dgrut_amd.tracer")
+cams = importlib.import_module("3dgrut_amd.cameras")
+io_colmap = importlib.import_module("3dgrut_amd.io_colmap")
+schedule = importlib.import_module("3dgrut_amd.schedule")
+capi = importlib.import_module("3dgrut_amd._capi")
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(GOLD, "host_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def R():
+    with open(os.path.join(GOLD, "host_golden.json")) as f:
+        return json.load(f)
+
+
+class _Raster:
+    """Recording tracer_wrapper returning the fixture's canned outputs (same role as the generator's FakeRaster)."""
+
+    def __init__(self, G):
+        self.c = {k: torch.as_tensor(G["ag_canned_" + k]) for k in ("rgba", "dist", "hits", "vis", "dens_grd", "sph_grd")}
+        self.trace_args = self.bwd_args = None
+
+    def trace(self, *a):
+        self.trace_args = a
+        return self.c["rgba"].clone(), self.c["dist"].clone(), self.c["hits"].clone(), self.c["vis"].clone()
+
+    def trace_bwd(self, *a):
+        self.bwd_args = a
+        return self.c["dens_grd"].clone(), self.c["sph_grd"].clone()
+
+    def collect_times(self):
+        return {"forward_render": 1.25}
+
+
+def _leaves(G):
+    t = lambda k: torch.as_tensor(G["ag_in_" + k]).clone()
+    leaves = {k: t(k).requires_grad_(True) for k in ("pos", "rot", "scl", "dns", "sph")}
+    rays = {k: t(k).requires_grad_(True) for k in ("ray_ori", "ray_dir")}
+    return leaves, rays
+
+
+def test_autograd_packing_argument_order_and_backward_slots(G, R):
+    """threedgut_tracer/tracer.py:159-286 driven with the same inputs and the same canned native outputs."""
+    rec = R["autograd"]
+    leaves, rays = _leaves(G)
+    w = _Raster(G)
+    poses = gut.tracer.SensorPose3D(T_world_sensors=[torch.as_tensor(G["ag_pose_start"]), torch.as_tensor(G["ag_pose_end"])],
+                                    timestamps_us=rec["ts"])
+    sensor = ("sensor-params-object",)
+    out = gut.Tracer._Autograd.apply(w, rec["frame_id"], rec["n_active_features"], rays["ray_ori"], rays["ray_dir"], leaves["pos"],
+                                     leaves["rot"], leaves["scl"], leaves["dns"], leaves["sph"], sensor, poses)
+    assert len(out) == 4
+    for k, o in zip(("rgba", "dist", "hits", "vis"), out):
+        assert np.array_equal(o.detach().numpy(), G["ag_out_" + k])
+    (out[0] * torch.as_tensor(G["ag_up_rgba_grd"])).sum().add((out[1] * torch.as_tensor(G["ag_up_dist_grd"])).sum()).backward()
+    ta, ba = w.trace_args, w.bwd_args
+    # positional layout of trace(): 12 arguments, trace_bwd(): the same 12 + rgba, rgba_grd, dist, dist_grd
+    assert len(ta) == rec["n_trace_args"] == 12 and len(ba) == rec["n_bwd_args"] == 16
+    assert ta[0] == rec["frame_id"] and ta[1] == rec["n_active_features"] and ba[0] == ta[0] and ba[1] == ta[1]
+    assert np.array_equal(ta[2].detach().numpy(), G["ag_particle_density"])     # [pos | dns | rot | scl | 0]
+    assert np.array_equal(ta[3].detach().numpy(), G["ag_particle_radiance"])
+    assert np.array_equal(ba[2].detach().numpy(), G["ag_particle_density"]) and np.array_equal(ba[3].detach().numpy(), G["ag_particle_radiance"])
+    assert np.array_equal(ta[4].detach().numpy(), G["ag_in_ray_ori"]) and np.array_equal(ta[5].detach().numpy(), G["ag_in_ray_dir"])
+    # slot 6 is ray_time: the reference passes an int64 [1,H,W,1] tensor no kernel reads; this build passes None (documented)
+    assert rec["trace_args"][6]["dtype"] == "int64" and ta[6] is None and ba[6] is None
+    assert ta[7] is sensor and ba[7] is sensor and rec["sensor_is_passed_through"]
+    assert [int(ta[8]), int(ta[9])] == rec["ts"] and [int(ba[8]), int(ba[9])] == rec["ts"]
+    assert np.array_equal(np.asarray(ta[10]), G["ag_pose_start"]) and np.array_equal(np.asarray(ta[11]), G["ag_pose_end"])
+    assert np.array_equal(ba[12].detach().numpy(), G["ag_bwd_rgba"]) and np.array_equal(ba[13].detach().numpy(), G["ag_bwd_rgba_grd"])
+    assert np.array_equal(ba[14].detach().numpy(), G["ag_bwd_dist"]) and np.array_equal(ba[15].detach().numpy(), G["ag_bwd_dist_grd"])
+    # the [3,1,4,3,1] split and the slots that carry gradients (pos, rot, scl, dns, sph); rays get none
+    for k, v in leaves.items():
+        assert np.array_equal(v.grad.numpy(), G["ag_grad_" + k]), k
+    assert rays["ray_ori"].grad is None and rays["ray_dir"].grad is None and rec["ray_grads_none"]
+
+
+def _batch_from_case(rec, c2w):
+    dummy = torch.zeros(1, 2, 2, 3)
+    vals = lambda k: np.array(rec[k]["values"], np.float32)
+    if rec["case"] == "list":
+        return gut.Batch(rays_ori=dummy, rays_dir=dummy, T_to_world=c2w[None], intrinsics=list(rec["input_intrinsics"]))
+    name = rec["case"].split("_", 1)[1]
+    if name == "int5":
+        st = 5
+    else:
+        st = cams.ShutterType[name]
+    res = np.array(rec["resolution"]["values"], np.int64)
+    if rec["fn"].startswith("fromOpenCVPinhole"):
+        K = dict(resolution=res, shutter_type=st, principal_point=vals("principal_point"), focal_length=vals("focal_length"),
+                 radial_coeffs=vals("radial_coeffs"), tangential_coeffs=vals("tangential_coeffs"),
+                 thin_prism_coeffs=vals("thin_prism_coeffs"))
+        return gut.Batch(rays_ori=dummy, rays_dir=dummy, T_to_world=c2w[None], intrinsics_OpenCVPinholeCameraModelParameters=K)
+    K = dict(resolution=res, shutter_type=st, principal_point=vals("principal_point"), focal_length=vals("focal_length"),
+             radial_coeffs=vals("radial_coeffs"), max_angle=rec["max_angle"]["value"])
+    return gut.Batch(rays_ori=dummy, rays_dir=dummy, T_to_world=c2w[None], intrinsics_OpenCVFisheyeCameraModelParameters=K)
+
+
+def test_shutter_enums_match_the_reference(R):
+    assert {m.name: int(m.value) for m in cams.ShutterType} == R["dataset_shutter_type"]        # camera_models.py:29-36 (1..5)
+    assert {m.name: int(m.value) for m in tracer_mod.ShutterType} == R["plugin_shutter_type"]   # bindings.cpp:87-92 (0..4)
+
+
+def test_create_camera_parameters_against_the_reference(R):
+    """tracer.py:361-431 with a recording plugin: same camera struct contents and pose for every intrinsics path and
+    every dataset shutter type (the round-1 bug: dataset GLOBAL=5 raised, 1 was read as LEFT_TO_RIGHT)."""
+    cc = R["create_camera_parameters"]
+    c2w = torch.tensor(cc["c2w"], dtype=torch.float32).reshape(4, 4)
+    seen = set()
+    for rec in cc["cases"]:
+        sensor, poses = gut.Tracer.create_camera_parameters(_batch_from_case(rec, c2w))
+        cam = sensor.cam
+        seen.add(rec["shutter_type"]["name"])
+        assert cam.shutter == rec["shutter_type"]["value"], rec["case"]
+        assert cam.model == (capi.CAMERA_PINHOLE if "Pinhole" in rec["fn"] else capi.CAMERA_FISHEYE)
+        f32 = lambda k: np.array(rec[k]["values"], np.float32)
+        assert np.array_equal(np.array(cam.principal_point[:], np.float32), f32("principal_point")), rec["case"]
+        assert np.array_equal(np.array(cam.focal_length[:], np.float32), f32("focal_length")), rec["case"]
+        nrad = len(rec["radial_coeffs"]["values"])
+        assert np.array_equal(np.array(cam.radial_coeffs[:nrad], np.float32), f32("radial_coeffs"))
+        if "Pinhole" in rec["fn"]:
+            assert np.array_equal(np.array(cam.tangential_coeffs[:], np.float32), f32("tangential_coeffs"))
+            assert np.array_equal(np.array(cam.thin_prism_coeffs[:], np.float32), f32("thin_prism_coeffs"))
+        else:
+            assert cam.max_angle == np.float32(rec["max_angle"]["value"])
+        assert poses.timestamps_us == rec["timestamps_us"]
+        assert np.array_equal(np.asarray(poses.T_world_sensors[0], np.float32), np.array(rec["pose_start"], np.float32)), rec["case"]
+        assert np.array_equal(np.asarray(poses.T_world_sensors[1], np.float32), np.array(rec["pose_end"], np.float32))
+    assert seen == set(R["plugin_shutter_type"])
+
+
+def test_create_camera_parameters_rejects_what_the_reference_rejects(R):
+    cc = R["create_camera_parameters"]
+    c2w = torch.tensor(cc["c2w"], dtype=torch.float32).reshape(4, 4)
+    rec = next(r for r in cc["cases"] if r["case"] == "pinhole_GLOBAL")
+    assert cc["rejected"]["0"] == "KeyError" and cc["rejected"]["6"] == "KeyError"
+    for bad in (0, 6):
+        b = _batch_from_case(rec, c2w)
+        b.intrinsics_OpenCVPinholeCameraModelParameters["shutter_type"] = bad
+        with pytest.raises(KeyError):
+            gut.Tracer.create_camera_parameters(b)
+    b = _batch_from_case(rec, c2w)
+    b.intrinsics_OpenCVPinholeCameraModelParameters["shutter_type"] = tracer_mod.ShutterType.GLOBAL   # plugin enum: wrong type
+    with pytest.raises(KeyError):
+        gut.Tracer.create_camera_parameters(b)
+    dummy = torch.zeros(1, 2, 2, 3)
+    with pytest.raises((ValueError, AttributeError)):   # the reference trips over gpu_batch.keys() (AttributeError)
+        gut.Tracer.create_camera_parameters(gut.Batch(rays_ori=dummy, rays_dir=dummy, T_to_world=c2w[None]))
+
+
+def test_reference_shaped_dataset_batch_is_accepted():
+    """A batch in the shape the reference's COLMAP dataset emits (`params.to_dict()`: numpy arrays turned into lists,
+    the dataset enum member under "shutter_type", dataset_colmap.py:138-183)."""
+    K = dict(resolution=[1237, 822], shutter_type=cams.ShutterType.GLOBAL, principal_point=[np.float32(618.5), np.float32(411.0)],
+             focal_length=[np.float32(1040.5), np.float32(1041.75)], radial_coeffs=[np.float32(0)] * 6,
+             tangential_coeffs=[np.float32(0)] * 2, thin_prism_coeffs=[np.float32(0)] * 4)
+    dummy = torch.zeros(1, 2, 2, 3)
+    sensor, _ = gut.Tracer.create_camera_parameters(
+        gut.Batch(rays_ori=dummy, rays_dir=dummy, T_to_world=torch.eye(4)[None], intrinsics_OpenCVPinholeCameraModelParameters=K))
+    assert sensor.cam.shutter == int(tracer_mod.ShutterType.GLOBAL) == 4
+    K["shutter_type"] = cams.ShutterType.ROLLING_TOP_TO_BOTTOM
+    sensor, _ = gut.Tracer.create_camera_parameters(
+        gut.Batch(rays_ori=dummy, rays_dir=dummy, T_to_world=torch.eye(4)[None], intrinsics_OpenCVPinholeCameraModelParameters=K))
+    assert sensor.cam.shutter == int(tracer_mod.ShutterType.ROLLING_TOP_TO_BOTTOM) == 0
+    # the repo's own builders emit the dataset numbering
+    assert cams.pinhole_intrinsics_dict(8, 8, 4.0, 4.0)["shutter_type"] == 5
+    assert cams.fisheye_intrinsics_dict(8, 8, 4.0, 4.0)["shutter_type"] == 5
+
+
+def test_render_output_dict_against_the_reference(G, R):
+    """Tracer.render (tracer.py:304-351) with the fake native module: same keys, shapes and values."""
+    rec = R["render"]
+    assert rec["ok"]
+    t = lambda k: torch.as_tensor(G["ag_in_" + k])
+
+    class Gaussians:
+        num_gaussians = int(G["ag_in_pos"].shape[0])
+        n_active_features = 2
+        positions = t("pos")
+        def get_rotation(self): return t("rot")
+        def get_scale(self): return t("scl")
+        def get_density(self): return t("dns")
+        def get_features(self): return t("sph")
+        def background(self, T_to_world, rays_d, rgb, opacity, train):
+            self.train = train
+            return rgb + 0.25 * (1.0 - opacity), opacity
+
+    tr = gut.Tracer.__new__(gut.Tracer)
+    tr.tracer_wrapper = _Raster(G)
+    gs = Gaussians()
+    c2w = torch.tensor(R["create_camera_parameters"]["c2w"], dtype=torch.float32).reshape(4, 4)
+    batch = gut.Batch(rays_ori=t("ray_ori"), rays_dir=t("ray_dir"), T_to_world=c2w[None], intrinsics=[100.0, 110.0, 3.5, 2.5])
+    out = tr.render(gs, batch, train=True, frame_id=9)
+    assert list(out.keys()) == rec["keys"]
+    assert out["frame_time_ms"] == rec["frame_time_ms"] and tr.tracer_wrapper.trace_args[0] == rec["frame_id"]
+    assert gs.train is rec["background_train"]
+    for k, shp in rec["shapes"].items():
+        if shp is not None:
+            assert list(out[k].shape) == shp, k
+            assert np.array_equal(out[k].detach().numpy(), G["render_" + k]), k
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_pinhole_rays_against_the_reference(G, tag):
+    """datasets/utils.py:39-59 (float64) vs cameras.pinhole_rays (float32 output)."""
+    w, h, fx, fy = G[f"rays_{tag}_whff"]
+    ro, rd = cams.pinhole_rays(int(w), int(h), fx, fy)
+    ref_d = G[f"rays_{tag}_dir"].reshape(1, int(h), int(w), 3)
+    assert np.array_equal(rd, ref_d.astype(np.float32))           # the dataset casts to float32 (dataset_colmap.py:151)
+    assert np.array_equal(ro, G[f"rays_{tag}_ori"].reshape(1, int(h), int(w), 3).astype(np.float32))
+
+
+@pytest.mark.parametrize("tag", ["zero", "dist"])
+def test_fisheye_rays_against_the_reference(G, tag):
+    """camera_models.py:156-248 (float32 torch, 3 Newton steps) vs cameras.fisheye_rays (float64 numpy, cast)."""
+    w, h, fx, fy, cx, cy, max_angle = G[f"fisheye_{tag}_params"]
+    w, h = int(w), int(h)
+    # the reference evaluates everything from float32 focal lengths / principal point
+    fx, fy, cx, cy = [float(np.float32(v)) for v in (fx, fy, cx, cy)]
+    assert abs(cams.fisheye_max_angle(w, h, fx, fy, cx, cy) - max_angle) <= 1e-6 * max_angle   # dataset_colmap.py:167-172
+    ro, rd = cams.fisheye_rays(w, h, fx, fy, cx, cy, radial=G[f"fisheye_{tag}_radial"])
+    ref = G[f"fisheye_{tag}_dir"]
+    assert rd.shape == ref.shape and not ro.any()
+    assert np.abs(rd - ref).max() <= 2e-6     # float32 reference arithmetic vs float64 here: a few ulp of a unit vector
+
+
+def test_max_radius_rule(G):
+    for w, h, cx, cy, expect in G["max_radius_cases"]:
+        mx, my = max(cx, w - cx), max(cy, h - cy)
+        assert abs(np.hypot(mx, my) - expect) <= 1e-9 * expect
+        got = cams.fisheye_max_angle(w, h, 700.0, 710.0, cx, cy)
+        assert abs(got - max(2 * expect / 700.0, 2 * expect / 710.0) / 2) <= 1e-9
+
+
+@pytest.mark.parametrize("fmt", ["bin", "txt"])
+def test_colmap_readers_against_the_reference(G, R, fmt):
+    """datasets/utils.py:258-566 on tests/golden/colmap_model (written by the generator in COLMAP's documented layouts)."""
+    d = os.path.join(GOLD, "colmap_model", fmt)
+    rec = R["colmap"][fmt]
+    if fmt == "bin":
+        cams_ = io_colmap.read_cameras_binary(os.path.join(d, "cameras.bin"))
+        imgs = io_colmap.read_images_binary(os.path.join(d, "images.bin"))
+        xyz, rgb, err = io_colmap.read_points3D_binary(os.path.join(d, "points3D.bin"))
+    else:
+        cams_ = io_colmap.read_cameras_text(os.path.join(d, "cameras.txt"))
+        imgs = io_colmap.read_images_text(os.path.join(d, "images.txt"))
+        xyz, rgb, err = io_colmap.read_points3D_text(os.path.join(d, "points3D.txt"))
+    assert len(cams_) == len(rec["cameras"])
+    for c in rec["cameras"]:
+        m = cams_[c["id"]]
+        assert (m.model, m.width, m.height) == (c["model"], c["width"], c["height"])
+        assert np.array_equal(np.asarray(m.params, np.float64), np.array(c["params"], np.float64))
+    # same ORDER (sorted by image name): the every-8th train/test split indexes it (dataset_colmap.py:81-91)
+    assert [i.name for i in imgs] == [i["name"] for i in rec["images"]]
+    for got, exp in zip(imgs, rec["images"]):
+        assert got.id == exp["id"] and got.camera_id == exp["camera_id"]
+        assert np.array_equal(np.asarray(got.qvec, np.float64), np.array(exp["qvec"]))
+        assert np.array_equal(np.asarray(got.tvec, np.float64), np.array(exp["tvec"]))
+    assert np.array_equal(xyz, G[f"colmap_{fmt}_xyz"])
+    assert np.array_equal(rgb.astype(np.float64), G[f"colmap_{fmt}_rgb"])
+    assert np.array_equal(err.reshape(-1), G[f"colmap_{fmt}_err"].reshape(-1))
+
+
+def test_qvec_to_rotation_and_scene_extent(G):
+    for q, Rm in zip(G["qvec_in"], G["qvec_so3"]):
+        assert np.abs(io_colmap.qvec_to_rotation(q) - Rm).max() <= 1e-15
+    cc = G["center_diag_in"]
+    centre = cc.mean(0)
+    assert np.allclose(centre, G["center_diag_center"], atol=0, rtol=1e-15)
+    assert abs(np.linalg.norm(cc - centre, axis=1).max() - float(G["center_diag_diag"])) <= 1e-15
+
+
+def test_sh_constants_against_the_reference(G):
+    """threedgrut/utils/render.py: the constants compiled into the kernels / oracle (gut_project.hip, gut_oracle.c)."""
+    prt = importlib.import_module("oracle.per_ray_torch")
+    assert prt._C0 == float(G["sh_C0"]) and prt._C1 == float(G["sh_C1"])
+    assert np.array_equal(np.array(prt._C2), G["sh_C2"]) and np.array_equal(np.array(prt._C3), G["sh_C3"])
+    src = open(os.path.join(os.path.dirname(GOLD), "..", "3dgrut_amd", "csrc", "gut_project.hip")).read()
+    osrc = open(os.path.join(os.path.dirname(GOLD), "..", "oracle", "gut_oracle.c")).read()
+    for c in [float(G["sh_C0"]), float(G["sh_C1"])] + [abs(float(v)) for v in G["sh_C2"]] + [abs(float(v)) for v in G["sh_C3"]]:
+        assert repr(c) + "f" in src and repr(c) + "f" in osrc, c
+    x = G["rgb2sh_in"]
+    assert np.allclose((x - 0.5) / 0.28209479177387814, G["rgb2sh_out"], rtol=1e-15, atol=0)   # io_colmap.initial_gaussians
+
+
+def test_position_lr_schedule_against_the_reference(G, R):
+    lr_i, lr_f, max_steps = G["sched_args"]
+    f = schedule.exponential_scheduler(lr_i, lr_f, int(max_steps))
+    got = np.array([f(int(s)) for s in G["sched_steps"]])
+    assert np.allclose(got, G["sched_lr"], rtol=1e-12, atol=0)
+    for rec in R["check_step_condition"]:
+        assert schedule.check_step_condition(*rec["args"]) is rec["result"], rec
+    assert R["skip_scheduler_returns_none"]
+    assert R["sh_degree_to_num_features"] == {"0": 3, "1": 12, "2": 27, "3": 48}   # the [N,48] radiance layout
+
+
+def test_train_schedule_follows_the_reference_iteration_order(G):
+    """trainer.py:745-765: the rate set after iteration g is sched(g); the SH degree rises after iterations 1000, 2000, 3000."""
+    extent = 4.5
+    s = schedule.TrainSchedule(scene_extent=extent)
+    assert s.n_active_features == 0 and abs(s.position_lr - 0.00016 * extent) < 1e-18
+    ref = dict(zip([int(v) for v in G["sched_steps"]], G["sched_lr"]))
+    degs = {}
+    for g in range(0, 4002):
+        lr, deg = s.after_optimizer_step(g)
+        if g in ref:
+            assert abs(lr - ref[g]) <= 1e-12 * ref[g]
+        degs[g] = deg
+    assert degs[999] == 0 and degs[1000] == 1 and degs[1999] == 1 and degs[2000] == 2 and degs[3000] == 3 and degs[4001] == 3
