@@ -147,6 +147,42 @@ def cpu_baseline_per_ray_torch(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degr
                       f"value is extrapolated to the full image"}
 
 
+def launcher_command(argv, n_gpus, port, python=None):
+    """The command `bench.py --gpus N` re-issues itself as when it was started without a rank environment: one process per
+    GPU over RCCL, exactly the driver's own form (task contract)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(argv, n_gpus):
+    """Started as plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE): spawn the N rank processes as CHILDREN of this
+    process — which has not touched the GPU and never execs — relay rank 0's JSON line, and exit non-zero if any rank fails."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = launcher_command(argv, n_gpus, _free_port())
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not json_lines:
+        print(f"[bench] multi-GPU run failed (exit code {proc.returncode}, {len(json_lines)} JSON lines)", file=sys.stderr)
+        return proc.returncode or 1
+    print(json_lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,10 +210,15 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # nothing in this process has initialised the GPU yet (device_count() does not, on this image)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} started with WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON line on

@@ -767,11 +767,11 @@ static void eval_hit(const OracleParams* prm, const float* g, const float rows[3
 /* K6: render — gutRenderer.cuh:83-115, gutKBufferRenderer.cuh:108-170,217-292 (K=0),
  * rayPayload.cuh:110-129.  Also returns per-tile traversal counts (entries fetched before the
  * whole tile terminated) for the roofline statistics E_f. */
-void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W, int H,
                    const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir,
                    const uint32_t* ranges, const uint32_t* sorted_ids,
-                   float* rgba, float* dist, float* hits, uint64_t* traversed_out) {
+                   float* rgba, float* dist, float* hits, uint64_t* traversed_out, float* margins) {
     const PoseSet ps = make_pose_set(cam);
     const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
     uint64_t traversed_total = 0;
@@ -788,6 +788,7 @@ void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int 
                 float T = 1.0f, rgb[3] = {0, 0, 0}, dsum = 0.0f;
                 uint32_t nh = 0;
                 uint32_t k = beg;
+                float m_thr = 3.4028235e+38f, m_trm = 3.4028235e+38f, t_noise = 1.0f; /* decision margins, see oracle_render_margins */
                 for (; k < end && ray.alive; ++k) {
                     const uint32_t id = sorted_ids[k];
                     if (id == INVALID_IDX) break;
@@ -796,6 +797,22 @@ void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int 
                     quat_to_rows(g + 4, rows);
                     Hit h;
                     eval_hit(prm, g, rows, &ray, &h);
+                    float nu = 0.0f;
+                    if (margins) {
+                        /* fp32 noise of the response, in units of eps = 2^-24, for ANY evaluation order of this formula:
+                         * c = grd x gro carries an absolute error ~ eps |gro| per component (cancellation), so
+                         * delta(d2) ~ 2 sqrt(d2) eps |gro| and delta(resp)/resp = delta(d2)/2; plus exp's argument/result
+                         * rounding (d2/2 + 2). */
+                        const float gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
+                        nu = sqrtf(h.d2) * gn + 0.5f * h.d2 + 2.0f;
+                        const float eps = 5.9604645e-08f;
+                        const float mr = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu);
+                        if (mr < m_thr) m_thr = mr;
+                        if (h.resp > prm->min_kernel_density) {
+                            const float ma = fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu);
+                            if (ma < m_thr) m_thr = ma;
+                        }
+                    }
                     if ((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold)) {
                         const float* s = g + 8;
                         const float proj = h.grd[0] * -h.gro[0] + h.grd[1] * -h.gro[1] + h.grd[2] * -h.gro[2];
@@ -812,6 +829,12 @@ void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int 
                                 }
                                 nh++;
                             }
+                            if (margins) {
+                                /* relative noise of the running transmittance: every factor (1 - alpha) inherits alpha's */
+                                t_noise += h.alpha * nu / (1.0f - h.alpha) + 1.0f;
+                                const float mt = fabsf(T - prm->min_transmittance) / (prm->min_transmittance * 5.9604645e-08f * t_noise);
+                                if (mt < m_trm) m_trm = mt;
+                            }
                             if (T < prm->min_transmittance) ray.alive = 0;
                         }
                     }
@@ -821,10 +844,34 @@ void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int 
                 rgba[4 * pix + 3] = 1.0f - T;
                 dist[pix] = dsum;
                 hits[pix] = (float)nh;
+                if (margins) { margins[2 * pix] = m_thr; margins[2 * pix + 1] = m_trm; }
             }
         traversed_total += deepest;
     }
     if (traversed_out) *traversed_out = traversed_total;
+}
+
+void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+                   const float* density12, const float* feat,
+                   const float* ray_ori, const float* ray_dir,
+                   const uint32_t* ranges, const uint32_t* sorted_ids,
+                   float* rgba, float* dist, float* hits, uint64_t* traversed_out) {
+    render_impl(prm, cam, W, H, density12, feat, ray_ori, ray_dir, ranges, sorted_ids, rgba, dist, hits, traversed_out, NULL);
+}
+
+/* The same render, additionally exporting per pixel how close any accept/reject decision along the ray came to flipping
+ * (tests only: attributes colour differences between two fp32 evaluations of the same formula to threshold flips).
+ * margins[2*pix+0]: min over walked entries of |resp - min_response| / min_response and (when resp passed)
+ *                   |resp*sigma - min_alpha| / min_alpha, each divided by eps * nu, nu = the entry's fp32 noise estimate
+ *                   in eps units (see render_impl) — i.e. "how many noise widths away from a hit/no-hit flip";
+ * margins[2*pix+1]: the same for the running transmittance against min_transmittance (early-termination flips).
+ * The hit-distance window (tmin, tmax) is not tracked: tmin = 0 and tmax ~ 1e6 for rays inside the +-1e6 scene box. */
+void oracle_render_margins(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+                           const float* density12, const float* feat, const float* ray_ori, const float* ray_dir,
+                           const uint32_t* ranges, const uint32_t* sorted_ids,
+                           float* rgba, float* dist, float* hits, float* margins) {
+    for (size_t i = 0; i < (size_t)W * H * 2; ++i) margins[i] = 3.4028235e+38f;
+    render_impl(prm, cam, W, H, density12, feat, ray_ori, ray_dir, ranges, sorted_ids, rgba, dist, hits, NULL, margins);
 }
 
 /* K6, sorted variant (k_buffer_size = K > 0): render with a per-ray K-entry hit buffer kept sorted by hit distance —

@@ -149,6 +149,24 @@ def forward(cam: dict, W, H, density12, sph48, ray_ori, ray_dir, sh_degree=3, pa
     return out
 
 
+def render_margins(cam: dict, fwd: dict, params=None):
+    """Per-pixel decision margins of a forward() result's compositing (oracle_render_margins): [H,W,2] float32,
+    channel 0 = hit/no-hit thresholds (min_response, min_alpha), channel 1 = early termination (min_transmittance),
+    both in units of the estimated fp32 noise of the compared quantity (< ~1: a different but equally valid fp32 evaluation
+    of the same formula may decide differently)."""
+    L = lib()
+    prm = params or default_params()
+    c = make_camera(cam)
+    d12, sph, ro, rd, sh_degree, W, H = fwd["_inputs"]
+    rgba = np.zeros((H, W, 4), np.float32); dist = np.full((H, W, 1), 1e6, np.float32); hits = np.zeros((H, W, 1), np.float32)
+    margins = np.full((H, W, 2), np.finfo(np.float32).max, np.float32)
+    if fwd["M"]:
+        L.oracle_render_margins(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), _p(d12), _p(fwd["feat"]), _p(ro), _p(rd),
+                                _p(fwd["tile_ranges"]), _p(fwd["sorted_ids"]), _p(rgba), _p(dist), _p(hits), _p(margins))
+        assert np.array_equal(rgba, fwd["rgba"])
+    return margins
+
+
 def render_kbuffer(cam: dict, fwd: dict, K=16, params=None, max_order=0):
     """Sorted-variant compositing (k_buffer_size=K) on top of a forward() result's tile lists.  Returns rgba, dist, hits and,
     if max_order > 0, the per-pixel composited particle order (order_ids [P,max_order] int32 -1 padded, order_count [P])."""

@@ -181,3 +181,25 @@ def test_kbuffer_oracle_matches_ordered_autograd(K):
     assert np.abs(dist.numpy().reshape(H, W, 1) - kb["dist"]).max() <= 3e-5 * max(1.0, float(kb["dist"].max()))
     # hit distances composited in non-decreasing order once K covers the local overlap
     assert np.array_equal(kb["hits"][..., 0].reshape(-1), kb["order_count"].astype(np.float32))
+
+
+def test_decision_margins_flag_a_response_sitting_on_the_threshold():
+    """oracle_render_margins: one isotropic Gaussian on the optical axis whose density makes resp*sigma cross 1/255 at a known
+    pixel radius: pixels on that ring are flip-prone (margin < 4), pixels well inside or outside are not."""
+    W = H = 64
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64.0)
+    d12 = np.zeros((1, 12), np.float32)
+    d12[0, 3] = 0.5
+    d12[0, 4] = 1.0
+    d12[0, 8:11] = 0.3
+    sph = np.zeros((1, 48), np.float32)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"])
+    m = oracle.render_margins(view["oracle_cam"], ref)
+    assert m.shape == (H, W, 2) and ref["M"] > 0
+    hit = ref["hits"].reshape(H, W) > 0
+    assert hit.any() and (~hit).any()
+    # the boundary of the hit region is where the margin collapses; the centre and the far corner are calm
+    thr = m[..., 0]
+    edge = hit & ~(np.roll(hit, 1, 0) & np.roll(hit, -1, 0) & np.roll(hit, 1, 1) & np.roll(hit, -1, 1))
+    assert thr[H // 2, W // 2] > 1e4 and np.median(thr[edge]) < np.median(thr[hit & ~edge])
+    assert (thr[hit] < 4.0).mean() < 0.05

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import cams, rel_l2, scenes
+from tests.common import cams, check_colour_outliers, rel_l2, scenes
 
 pytestmark = pytest.mark.gpu
 gut = importlib.import_module("3dgrut_amd")
@@ -149,13 +149,11 @@ def test_full_size_frame_against_the_oracle(frame):
         got = frame["raster"].debug_buffer(key).cpu().numpy().view(np.uint32)
         exp = np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)
         assert np.array_equal(got, exp), f"{key}: {(got != exp).sum()} of {got.size} words differ"
-    # colours: 2e-4 as in test_gpu_parity; over a million pixels x ~100 blended hits a few responses sit within an ulp of the
-    # 1/255 alpha threshold and flip between "hit" and "no hit" (hardware exp/rcp vs libm), each flip moving its pixel by at
-    # most alpha_threshold * colour ~ 4e-3: allow that on <= 0.1 % of the pixels, never more than 1e-2
-    diff = np.abs(frame["rgba"].cpu().numpy() - ref["rgba"]).max(-1)
-    assert (diff > 2e-4).mean() <= 1e-3, f"{(diff > 2e-4).sum()} pixels off by more than 2e-4"
-    assert diff.max() <= 1e-2
-    assert (frame["hits"].cpu().numpy().reshape(H, W) != ref["hits"].reshape(H, W)).mean() <= 1e-3
+    # colours: 2e-4 as in test_gpu_parity.  Over a million pixels x ~100 blended hits some responses sit within fp32 noise of
+    # the min_response / min_alpha thresholds and flip between "hit" and "no hit" (hardware exp/rcp + FMA vs libm): such a
+    # pixel is excused ONLY if the oracle's own per-pixel decision margins say so (tests/common.check_colour_outliers)
+    margins = oracle.render_margins(ocam, ref)
+    check_colour_outliers(frame["rgba"].cpu().numpy(), frame["hits"].cpu().numpy(), ref, margins, label="bicycle_like_6M")
     assert frame["stats"]["traversed_fwd"] == ref["traversed_fwd"]
     # backward of the same frame: gradients w.r.t. the activated tracer inputs, relative L2 <= 2e-3 per parameter block
     rgba_grad = np.random.default_rng(4).normal(size=(H, W, 4)).astype(np.float32)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import cams, make_view, rel_l2, scenes
+from tests.common import cams, check_colour_outliers, make_view, rel_l2, scenes
 from tests.test_gpu_parity import DIST, _activated_grads, _oracle_inputs, _run_gpu
 
 pytestmark = pytest.mark.gpu
@@ -58,8 +58,12 @@ def test_random_configuration_matches_the_oracle(seed):
         assert np.array_equal(got, np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)), key
     out = res["out"]
     rgba = np.concatenate([out["pred_rgb"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
-    diff = np.abs(rgba - ref["rgba"]).max(-1)
-    assert (diff > 2e-4).mean() <= 1e-3 and diff.max() <= 1e-2
+    if ref["M"]:
+        margins = oracle.render_margins(view["oracle_cam"], ref)
+        check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"fuzz {seed}",
+                              max_prone=0.3)   # the ill-conditioned draws (needles, 2e-4 scales) have wide noise bands
+    else:
+        assert np.abs(rgba - ref["rgba"]).max() == 0.0
     st = raster.stats()
     assert st["traversed_fwd"] == ref["traversed_fwd"]
     if ref["M"] == 0:
