@@ -11,12 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  # override: dev experiments only
 
 GUT_ABI_VERSION = 1
-GUT_NUM_KERNEL_TIMERS = 9
+GUT_NUM_KERNEL_TIMERS = 10
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
 BWD_SKIP_EPILOGUE = 4
 OPT_LAZY_TILE_ORDER = 1
-KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer")
+KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer",
+                      "optimizer_early")
 
 SHUTTER_GLOBAL = 4
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
@@ -53,7 +54,7 @@ class GutStats(C.Structure):
     _fields_ = [
         ("num_particles", C.c_uint64), ("num_visible", C.c_uint64), ("num_intersections", C.c_uint64),
         ("num_tiles", C.c_uint64), ("num_pixels", C.c_uint64), ("traversed_fwd", C.c_uint64),
-        ("traversed_bwd", C.c_uint64), ("sort_end_bit", C.c_uint32), ("reserved", C.c_uint32),
+        ("traversed_bwd", C.c_uint64), ("sort_end_bit", C.c_uint32), ("binning_overflows", C.c_uint32),
     ]
 
 
@@ -61,7 +62,7 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
            "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
-           "gut_trace_bwd_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
+           "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
 
 _lib = None
 
@@ -109,6 +110,8 @@ def load():
     fptr = C.POINTER(C.c_float)
     lib.gut_optimize_after_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float, u32,
                                            vp, vp]
+    lib.gut_optimize_rows_without_gradient.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float,
+                                                       u32, vp]
     lib.gut_set_option.argtypes = [vp, i32, i32]
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -146,8 +147,31 @@ struct gut_context {
     DevBuf counters;
     uint32_t* host_count = nullptr;  // pinned
     hipEvent_t count_event = nullptr;  // the count read-back has landed (work queued behind it keeps the GPU busy meanwhile)
-    bool trains = false;               // a backward has run on this handle: forwards pre-clear the gradient rows
-    bool grad16_clean = false;         // ... and this says the rows are already zero when the backward starts
+    // rows without tiles are optimised early, on a low-priority side stream under the compositing kernels
+    // (gut_optimize_rows_without_gradient): ev_projected = projection AND binning of the cached forward have finished (tiles_count is
+    // final), ev_early_done = the side stream's pass has finished
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_projected = nullptr, ev_early_done = nullptr;
+    // the pass runs in two launches: the first block range under the forward compositor, the second under the backward
+    // compositor (queued by gut_trace_bwd_ex), so that the short, latency-bound loss kernels in between are left alone
+    struct EarlyArgs {
+        float *raw12, *raw_m, *raw_v, *sh48, *sh_m, *sh_v, *act12;
+        float lr12[12], lr48[48];
+        float beta1, beta2, eps;
+        uint32_t step, block_begin, block_end;
+    } early_args{};
+    bool early_part2_pending = false;
+    hipEvent_t ev_bwd_start = nullptr;
+    bool early_ran = false;           // the cached forward's rows without tiles already had their optimiser step
+    bool early_wait_pending = false;  // the main stream has not been ordered behind ev_early_done yet
+    bool grad16_zero = false;          // every row of grad16 is zero: true after a clear, false once K7 has added to it, true
+                                       // again when a per-Gaussian consumer (K8 / the optimiser kernel) has walked the rows
+                                       // that have tiles (they zero what they read)
+    // binning capacity: the forward is queued against m_capacity list slots before this frame's count is known
+    uint32_t m_capacity = 0, m_peak = 0, sort_n = 0;
+    uint64_t overflows = 0;
+    DevBuf zero_word, tile_ordered;
+    bool dbg_ordered_valid = false;
 
     // cached forward context (gutRenderer.cu:252-254, 413)
     bool have_forward = false;
@@ -163,8 +187,8 @@ struct gut_context {
     // per-kernel event boundaries: a ring of sets so that bench.py can average over its whole timed region
     static constexpr int kRing = 64;
     struct KevSet {
-        hipEvent_t e[14] = {};
-        bool fwd = false, bwd = false, opt = false;
+        hipEvent_t e[16] = {};
+        bool fwd = false, bwd = false, opt = false, early = false;
     };
     KevSet ring[kRing];
     int ring_cur = 0;    // set used by the most recent trace()
@@ -276,6 +300,8 @@ float drain_timers(std::deque<EventPair>& q) {
 
 }  // namespace
 
+static int launch_early_part2(gut_context* h, hipStream_t s);
+
 extern "C" {
 
 const char* gut_last_error(void) { return g_last_error.c_str(); }
@@ -349,10 +375,14 @@ void gut_destroy(gut_handle h) {
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
                       &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters, &h->ids_ordered,
-                      &h->dbg_keys_sorted, &h->dbg_ids_sorted};
+                      &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
+    if (h->ev_projected) (void)hipEventDestroy(h->ev_projected);
+    if (h->ev_early_done) (void)hipEventDestroy(h->ev_early_done);
+    if (h->ev_bwd_start) (void)hipEventDestroy(h->ev_bwd_start);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     (void)drain_timers(h->fwd_timers);
     (void)drain_timers(h->bwd_timers);
     for (auto& set : h->ring)
@@ -383,6 +413,13 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     const uint32_t n = num_particles;
     const int tiles = v.grid_x * v.grid_y;
     if ((uint64_t)tiles >= 0xFFFFFFFFull) return fail("gut_trace: too many tiles");
+    if (h->early_ran)
+        return fail("gut_trace: gut_optimize_rows_without_gradient was called for the previous forward but gut_optimize_after_bwd "
+                    "was not: that optimiser step is half applied");
+    if (h->early_wait_pending) {  // (only reachable after an error path; the optimiser call normally orders the streams)
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_early_done, 0));
+        h->early_wait_pending = false;
+    }
     h->have_forward = false;
     h->have_backward = false;
 
@@ -397,6 +434,11 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     HIP_TRY(h->trav_fwd.ensure(sizeof(uint32_t) * (size_t)tiles));
     HIP_TRY(h->trav_bwd.ensure(sizeof(uint32_t) * (size_t)tiles));
     HIP_TRY(h->tile_order.ensure(sizeof(uint32_t) * (size_t)tiles));
+    HIP_TRY(h->tile_ordered.ensure(sizeof(uint32_t) * (size_t)tiles));
+    if (!h->zero_word.p) {
+        HIP_TRY(h->zero_word.ensure(64));
+        HIP_TRY(hipMemsetAsync(h->zero_word.p, 0, 64, s));
+    }
     if (n) HIP_TRY(h->scan_temp.ensure(gut::scan_temp_bytes(n)));
 
     const bool timing = h->cfg.enable_kernel_timings != 0;
@@ -408,87 +450,134 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
         h->ring[h->ring_cur].fwd = false;
         h->ring[h->ring_cur].bwd = false;
         h->ring[h->ring_cur].opt = false;
+        h->ring[h->ring_cur].early = false;
     }
     auto mark = [&](int i) {
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
     };
 
     HIP_TRY(hipMemsetAsync(h->trav_bwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
+    HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
     mark(0);
     gut::launch_project(s, v, h->consts, n, num_active_features, d_particle_density, d_particle_radiance,
                         h->tiles_count.as<uint32_t>(), h->proj_pos.as<float>(), h->conic_opacity.as<float>(),
                         h->extent.as<float>(), h->depth.as<float>(), h->feat.as<float>(), d_particle_visibility,
                         h->counters.as<gut::Counters>());
     mark(1);
+    static const bool early_after_project = getenv("GUT_EARLY_AFTER_PROJECT") != nullptr;  // tuning experiments only
+    if (early_after_project) {
+        if (!h->ev_projected) HIP_TRY(hipEventCreateWithFlags(&h->ev_projected, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h->ev_projected, s));
+    }
+    const int end_bit = 32 + (int)bit_width_u32((uint32_t)tiles);
+    h->dbg_sorted_valid = false;
+    h->dbg_ordered_valid = false;
+    // device-side intersection count: the last element of the inclusive scan (a zero word when there are no particles)
+    const uint32_t* d_count = n ? h->tiles_offset.as<uint32_t>() + (n - 1) : h->zero_word.as<uint32_t>();
     uint32_t m = 0;
+    bool count_pending = false;
     if (n) {
         HIP_TRY(gut::run_scan(s, h->scan_temp.p, h->scan_temp.cap, h->tiles_count.as<uint32_t>(), h->tiles_offset.as<uint32_t>(), n));
-        // intersection count readback: the one host sync of the path (gutRenderer.cu:313-321)
-        HIP_TRY(hipMemcpyAsync(h->host_count, h->tiles_offset.as<uint32_t>() + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        // intersection count read-back (gutRenderer.cu:313-321).  The reference blocks on it before it can size the
+        // binning buffers; here the copy is queued and the host only waits for it AFTER the rest of the forward has been
+        // queued against a capacity taken from the previous frames (m_capacity), so the GPU never idles on the host.
+        HIP_TRY(hipMemcpyAsync(h->host_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         if (!h->count_event) HIP_TRY(hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(h->count_event, s));
-        // work that does not depend on the count is queued BEHIND the read-back and runs while the host waits for it:
-        // the tile-range clear and, on a handle that trains, the clear of the 64-byte gradient rows of the coming backward
-        HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
-        h->grad16_clean = false;
-        if (h->trains) {
-            HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)n));
-            HIP_TRY(hipMemsetAsync(h->grad16.p, 0, sizeof(float) * 16 * (size_t)n, s));
-            h->grad16_clean = true;
-        }
-        HIP_TRY(hipEventSynchronize(h->count_event));
-        m = *h->host_count;
-    } else {
-        HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
+        count_pending = true;
     }
     mark(2);
-    const int end_bit = 32 + (int)bit_width_u32((uint32_t)tiles);
+    // One binning + compositing pass over `sort_n` list slots (>= the real count, the tail is padding).  Returns through
+    // the lambda so that the rare overflow can run it a second time.
+    auto bin_and_render = [&](uint32_t sort_n, bool lazy) -> int {
+        h->lazy_order = lazy;
+        if (sort_n) {
+            HIP_TRY(h->keys_unsorted.ensure(sizeof(uint64_t) * (size_t)sort_n));
+            HIP_TRY(h->keys_sorted.ensure(sizeof(uint64_t) * (size_t)sort_n));
+            HIP_TRY(h->ids_unsorted.ensure(sizeof(uint32_t) * (size_t)sort_n));
+            HIP_TRY(h->ids_sorted.ensure(sizeof(uint32_t) * (size_t)sort_n));
+            gut::launch_expand(s, v, h->consts, n, h->tiles_offset.as<uint32_t>(), h->proj_pos.as<float>(),
+                               h->conic_opacity.as<float>(), h->extent.as<float>(), h->depth.as<float>(),
+                               h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>(), sort_n);
+            gut::launch_pad_keys(s, d_count, sort_n, h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>());
+            mark(3);
+            if (lazy) {
+                HIP_TRY(h->sort_temp.ensure(gut::sort_tiles_temp_bytes(sort_n, end_bit)));
+                HIP_TRY(h->ids_ordered.ensure(sizeof(uint32_t) * (size_t)sort_n));
+                HIP_TRY(gut::run_sort_tiles(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(),
+                                            h->keys_sorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(),
+                                            sort_n, end_bit));
+            } else {
+                HIP_TRY(h->sort_temp.ensure(gut::sort_temp_bytes(sort_n, end_bit)));
+                HIP_TRY(gut::run_sort(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(), h->keys_sorted.as<uint64_t>(),
+                                      h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), sort_n, end_bit));
+            }
+            mark(4);
+            gut::launch_tile_ranges(s, sort_n, h->keys_sorted.as<uint64_t>(), h->ranges.as<uint32_t>());
+        } else {
+            mark(3);
+            mark(4);
+        }
+        mark(5);
+        // the side-stream optimiser pass may start here: tiles_count is final and the HBM-bound part of the forward
+        // (projection, scan, expansion, sort) is over — what follows on this stream is VALU-bound compositing
+        if (!early_after_project) {
+            if (!h->ev_projected) HIP_TRY(hipEventCreateWithFlags(&h->ev_projected, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(h->ev_projected, s));
+        }
+        // with zero intersections the reference returns its freshly initialised outputs (gutRenderer.cu:323-325);
+        // running the compositor over empty ranges writes exactly those values
+        if (h->cfg.k_buffer_size > 0) {
+            HIP_TRY(hipMemsetAsync(h->trav_fwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
+            gut::launch_render_sorted(s, v, h->consts, h->cfg.k_buffer_size, d_particle_density, h->feat.as<float>(), d_ray_origin,
+                                      d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_count,
+                                      d_ray_radiance_density, d_ray_hit_distance, d_ray_hit_count);
+        } else {
+            gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
+                               h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_count, d_ray_radiance_density,
+                               d_ray_hit_distance, d_ray_hit_count, h->trav_fwd.as<uint32_t>(),
+                               lazy ? h->keys_sorted.as<uint64_t>() : nullptr, lazy ? h->ids_ordered.as<uint32_t>() : nullptr,
+                               lazy ? h->tile_ordered.as<uint32_t>() : nullptr);
+        }
+        return 0;
+    };
     // the k-buffer variant walks whole lists: it keeps the full sort
     // ... and frames whose tile lists are so long on average that re-scanning them per 512 ordered entries cannot pay
-    const bool lazy = h->lazy_enabled && h->cfg.k_buffer_size == 0 && m != 0 && (uint64_t)m < (uint64_t)tiles * 16384ull;
-    h->lazy_order = lazy;
-    h->dbg_sorted_valid = false;
-    if (m) {
-        HIP_TRY(h->keys_unsorted.ensure(sizeof(uint64_t) * (size_t)m));
-        HIP_TRY(h->keys_sorted.ensure(sizeof(uint64_t) * (size_t)m));
-        HIP_TRY(h->ids_unsorted.ensure(sizeof(uint32_t) * (size_t)m));
-        HIP_TRY(h->ids_sorted.ensure(sizeof(uint32_t) * (size_t)m));
-        gut::launch_expand(s, v, h->consts, n, h->tiles_offset.as<uint32_t>(), h->proj_pos.as<float>(),
-                           h->conic_opacity.as<float>(), h->extent.as<float>(), h->depth.as<float>(),
-                           h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>());
-        mark(3);
-        if (lazy) {
-            HIP_TRY(h->sort_temp.ensure(gut::sort_tiles_temp_bytes(m, end_bit)));
-            HIP_TRY(h->ids_ordered.ensure(sizeof(uint32_t) * (size_t)m));
-            // unwritten positions read as padding ids (end of list) in the backward
-            HIP_TRY(hipMemsetAsync(h->ids_ordered.p, 0xFF, sizeof(uint32_t) * (size_t)m, s));
-            HIP_TRY(gut::run_sort_tiles(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(),
-                                        h->keys_sorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m,
-                                        end_bit));
-        } else {
-            HIP_TRY(h->sort_temp.ensure(gut::sort_temp_bytes(m, end_bit)));
-            HIP_TRY(gut::run_sort(s, h->sort_temp.p, h->sort_temp.cap, h->keys_unsorted.as<uint64_t>(), h->keys_sorted.as<uint64_t>(),
-                                  h->ids_unsorted.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, end_bit));
+    auto want_lazy = [&](uint64_t count) {
+        return h->lazy_enabled && h->cfg.k_buffer_size == 0 && count != 0 && count < (uint64_t)tiles * 16384ull;
+    };
+    if (n && h->m_capacity == 0) {
+        // first frame on this handle (or after a reset): nothing to size from, wait for the count like the reference
+        HIP_TRY(hipEventSynchronize(h->count_event));
+        count_pending = false;
+        m = *h->host_count;
+        if (bin_and_render(m, want_lazy(m))) return 1;
+    } else {
+        const uint32_t sort_n = n ? h->m_capacity : 0u;
+        if (bin_and_render(sort_n, want_lazy(sort_n))) return 1;
+        if (count_pending) {
+            HIP_TRY(hipEventSynchronize(h->count_event));  // everything is queued: the GPU keeps working while the host waits here
+            count_pending = false;
+            m = *h->host_count;
         }
-        mark(4);
-        gut::launch_tile_ranges(s, m, h->keys_sorted.as<uint64_t>(), h->ranges.as<uint32_t>());
-    } else {
-        mark(3);
-        mark(4);
+        if (m > sort_n) {
+            // the frame has more intersections than the capacity assumed: entries beyond it were dropped by the expansion.
+            // Redo binning and compositing with the real count (same stream: the second pass simply overwrites the first).
+            HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
+            h->overflows++;
+            if (bin_and_render(m, want_lazy(m))) return 1;
+            h->sort_n = m;
+        } else {
+            h->sort_n = sort_n;
+        }
     }
-    mark(5);
-    // with zero intersections the reference returns its freshly initialised outputs (gutRenderer.cu:323-325);
-    // running the compositor over empty ranges writes exactly those values
-    if (h->cfg.k_buffer_size > 0) {
-        HIP_TRY(hipMemsetAsync(h->trav_fwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
-        gut::launch_render_sorted(s, v, h->consts, h->cfg.k_buffer_size, d_particle_density, h->feat.as<float>(), d_ray_origin,
-                                  d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m,
-                                  d_ray_radiance_density, d_ray_hit_distance, d_ray_hit_count);
-    } else {
-        gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
-                           h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), m, d_ray_radiance_density, d_ray_hit_distance,
-                           d_ray_hit_count, h->trav_fwd.as<uint32_t>(), lazy ? h->keys_sorted.as<uint64_t>() : nullptr,
-                           lazy ? h->ids_ordered.as<uint32_t>() : nullptr);
+    if (n && h->m_capacity == 0) h->sort_n = m;
+    // capacity for the next frame: a little above the largest recent count (slowly forgetting old peaks), multiple of 4096
+    {
+        const double decayed = (double)h->m_peak * 0.999;
+        h->m_peak = (uint32_t)((double)m > decayed ? (double)m : decayed);
+        const uint64_t want = (uint64_t)((double)h->m_peak * 1.03) + 4096ull;
+        h->m_capacity = m || h->m_peak ? (uint32_t)(((want + 4095ull) / 4096ull) * 4096ull) : 0u;
     }
     mark(6);
     HIP_TRY(hipGetLastError());
@@ -564,7 +653,11 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
     if (memcmp(&v, &h->view, sizeof(v)) != 0) return fail("gut_trace_bwd: camera differs from the cached forward");
     const uint32_t n = h->n;
     if (n == 0) return 0;
-    HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)n));
+    {
+        const void* before = h->grad16.p;
+        HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)n));
+        if (h->grad16.p != before) h->grad16_zero = false;  // fresh allocation
+    }
 
     const bool timing = h->cfg.enable_kernel_timings != 0;
     EventPair* total = timing ? arm_timer(h->bwd_timers, s) : nullptr;
@@ -573,9 +666,11 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
     };
     mark(8);
-    if (!h->grad16_clean) HIP_TRY(hipMemsetAsync(h->grad16.p, 0, sizeof(float) * 16 * (size_t)n, s));
-    h->grad16_clean = false;
-    h->trains = true;
+    // the gradient rows are zero already unless this is the first backward or the previous one was never consumed (every
+    // per-Gaussian consumer below zeroes the rows it reads, so there is no 64 N-byte clear per step)
+    if (!h->grad16_zero) HIP_TRY(hipMemsetAsync(h->grad16.p, 0, h->grad16.cap, s));
+    h->grad16_zero = false;
+    if (launch_early_part2(h, s)) return 1;
     mark(9);
     if (h->m && h->cfg.k_buffer_size > 0) {
         if (!d_ray_hit_distance) return fail("gut_trace_bwd: the sorted variant needs d_ray_hit_distance");
@@ -590,18 +685,22 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
                                h->ranges.as<uint32_t>(), (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(),
                                d_ray_radiance_density,
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
-                               h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>());
+                               h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>(),
+                               h->lazy_order ? h->tile_ordered.as<uint32_t>() : nullptr);
     }
     mark(10);
     if (flags & GUT_BWD_SKIP_EPILOGUE) {
         // the caller folds the per-Gaussian epilogue into its optimiser step (gut_optimize_after_bwd)
-    } else if (flags & GUT_BWD_COMPACT_RADIANCE_GRADS)
-        gut::launch_project_bwd_compact(s, n, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
-                                        h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad);
-    else
-        gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
-                                h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad,
-                                (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0);
+    } else {
+        if (flags & GUT_BWD_COMPACT_RADIANCE_GRADS)
+            gut::launch_project_bwd_compact(s, n, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
+                                            h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad);
+        else
+            gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
+                                    h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad,
+                                    (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0);
+        h->grad16_zero = true;  // the epilogue zeroed every row K7 could have touched (the rows with tiles)
+    }
     mark(11);
     HIP_TRY(hipGetLastError());
     if (total) {
@@ -627,19 +726,98 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     if (h->n == 0) return 0;
     if (!d_camera_position || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48)
         return fail("gut_optimize_after_bwd: null pointer argument");
+    if (h->early_ran && d_visibility)
+        return fail("gut_optimize_after_bwd: a visibility mask cannot follow gut_optimize_rows_without_gradient");
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
+    if (launch_early_part2(h, s)) return 1;  // (normally queued by gut_trace_bwd_ex already)
     const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[12] && h->kev[13];
     if (timing) (void)hipEventRecord(h->kev[12], s);
     gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, d_camera_position, h->grad16.as<float>(), h->tiles_count.as<uint32_t>(),
                                      h->feat.as<float>(), d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12, lr48, beta1, beta2,
-                                     eps, step, d_visibility, d_act12_out);
+                                     eps, step, d_visibility, d_act12_out, h->early_ran);
     HIP_TRY(hipGetLastError());
     if (timing) {
         (void)hipEventRecord(h->kev[13], s);
         h->ring[h->ring_cur].opt = true;
     }
-    h->have_backward = false;  // the gradient rows are consumed
+    if (h->early_wait_pending) {  // whatever follows on this stream (the next forward) also sees the side stream's rows
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_early_done, 0));
+        h->early_wait_pending = false;
+    }
+    h->early_ran = false;
+    h->have_backward = false;  // the gradient rows are consumed ...
+    h->grad16_zero = true;     // ... and left zero by the kernel
+    return 0;
+}
+
+int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48,
+                                       float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
+                                       float eps, uint32_t step, float* d_act12_out) {
+    if (!h) return fail("gut_optimize_rows_without_gradient: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (!h->have_forward || h->fwd_stream != s)
+        return fail("gut_optimize_rows_without_gradient: no forward context on this stream (call gut_trace first, same stream)");
+    if (h->early_ran) return fail("gut_optimize_rows_without_gradient: already called for this forward");
+    if (h->have_backward) return fail("gut_optimize_rows_without_gradient: call it between gut_trace and gut_trace_bwd_ex");
+    if (h->n == 0) return 0;
+    if (!d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48)
+        return fail("gut_optimize_rows_without_gradient: null pointer argument");
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
+    if (!h->side_stream) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
+    }
+    if (!h->ev_early_done) HIP_TRY(hipEventCreateWithFlags(&h->ev_early_done, hipEventDisableTiming));
+    HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_projected, 0));
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[14] && h->kev[15];
+    if (timing) (void)hipEventRecord(h->kev[14], h->side_stream);
+    static int split_percent = -1;
+    if (split_percent < 0) {
+        const char* e = getenv("GUT_EARLY_SPLIT");  // tuning experiments only
+        split_percent = e ? atoi(e) : 25;
+        if (split_percent < 0 || split_percent > 100) split_percent = 25;
+    }
+    const uint32_t nblocks = (h->n + gut::kBlock - 1) / gut::kBlock;
+    const uint32_t first = (uint32_t)((uint64_t)nblocks * (uint32_t)split_percent / 100u);
+    gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), d_raw12, d_raw_m, d_raw_v, d_sh48,
+                                           d_sh_m, d_sh_v, lr12, lr48, beta1, beta2, eps, step, d_act12_out, 0, first);
+    HIP_TRY(hipGetLastError());
+    gut_context::EarlyArgs& ea = h->early_args;
+    ea.raw12 = d_raw12; ea.raw_m = d_raw_m; ea.raw_v = d_raw_v; ea.sh48 = d_sh48; ea.sh_m = d_sh_m; ea.sh_v = d_sh_v;
+    ea.act12 = d_act12_out;
+    memcpy(ea.lr12, lr12, sizeof(ea.lr12));
+    memcpy(ea.lr48, lr48, sizeof(ea.lr48));
+    ea.beta1 = beta1; ea.beta2 = beta2; ea.eps = eps; ea.step = step; ea.block_begin = first; ea.block_end = nblocks;
+    h->early_part2_pending = first < nblocks;
+    if (timing) {
+        (void)hipEventRecord(h->kev[15], h->side_stream);  // re-recorded behind the second launch
+        h->ring[h->ring_cur].early = true;
+    }
+    HIP_TRY(hipEventRecord(h->ev_early_done, h->side_stream));
+    h->early_ran = true;
+    h->early_wait_pending = true;
+    return 0;
+}
+
+// second launch of the early optimiser pass, ordered behind the point of the main stream where the backward compositor starts
+static int launch_early_part2(gut_context* h, hipStream_t s) {
+    if (!h->early_part2_pending) return 0;
+    h->early_part2_pending = false;
+    if (!h->ev_bwd_start) HIP_TRY(hipEventCreateWithFlags(&h->ev_bwd_start, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->ev_bwd_start, s));
+    HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_bwd_start, 0));
+    const gut_context::EarlyArgs& ea = h->early_args;
+    gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), ea.raw12, ea.raw_m, ea.raw_v, ea.sh48,
+                                           ea.sh_m, ea.sh_v, ea.lr12, ea.lr48, ea.beta1, ea.beta2, ea.eps, ea.step, ea.act12,
+                                           ea.block_begin, ea.block_end);
+    HIP_TRY(hipGetLastError());
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[14] && h->kev[15];
+    if (timing) (void)hipEventRecord(h->kev[15], h->side_stream);
+    HIP_TRY(hipEventRecord(h->ev_early_done, h->side_stream));
     return 0;
 }
 
@@ -687,6 +865,7 @@ int gut_kernel_times(gut_handle h, float* ms8) {
         ms8[7] = span(10, 11);  // project backward
     }
     if (h->ring[h->ring_cur].opt) ms8[8] = span(12, 13);  // one-pass optimiser (gut_optimize_after_bwd)
+    if (h->ring[h->ring_cur].early) ms8[9] = span(14, 15);  // rows without tiles, on the side stream
     return 0;
 }
 
@@ -696,12 +875,12 @@ int gut_kernel_times_mean(gut_handle h, float* ms8, int32_t* count) {
     if (!h->cfg.enable_kernel_timings) return fail("gut_kernel_times_mean: enable_kernel_timings is off");
     double sum[GUT_NUM_KERNEL_TIMERS] = {};
     int cnt[GUT_NUM_KERNEL_TIMERS] = {};
-    static const int kA[GUT_NUM_KERNEL_TIMERS] = {0, 1, 2, 3, 4, 5, 9, 10, 12};
-    static const int kB[GUT_NUM_KERNEL_TIMERS] = {1, 2, 3, 4, 5, 6, 10, 11, 13};
+    static const int kA[GUT_NUM_KERNEL_TIMERS] = {0, 1, 2, 3, 4, 5, 9, 10, 12, 14};
+    static const int kB[GUT_NUM_KERNEL_TIMERS] = {1, 2, 3, 4, 5, 6, 10, 11, 13, 15};
     for (int k = 0; k < h->ring_count; ++k) {
         const auto& set = h->ring[(h->ring_cur - k + 2 * gut_context::kRing) % gut_context::kRing];
         for (int i = 0; i < GUT_NUM_KERNEL_TIMERS; ++i) {
-            const bool ok = i < 6 ? set.fwd : (i < 8 ? set.bwd : set.opt);
+            const bool ok = i < 6 ? set.fwd : (i < 8 ? set.bwd : (i == 8 ? set.opt : set.early));
             if (!ok || !set.e[kA[i]] || !set.e[kB[i]]) continue;
             float ms = 0.f;
             if (hipEventSynchronize(set.e[kB[i]]) == hipSuccess && hipEventElapsedTime(&ms, set.e[kA[i]], set.e[kB[i]]) == hipSuccess) {
@@ -737,6 +916,7 @@ int gut_get_stats(gut_handle h, GutStats* out) {
     out->traversed_fwd = c.traversed_fwd;
     out->traversed_bwd = c.traversed_bwd;
     out->sort_end_bit = (uint32_t)h->end_bit;
+    out->binning_overflows = (uint32_t)h->overflows;
     return 0;
 }
 
@@ -779,6 +959,16 @@ int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes) {
         else { *d_ptr = h->ids_sorted.p; *bytes = 4 * m; }
         break;
     case GUT_BUF_ORDERED_IDS:
+        if (h->lazy_order && !h->dbg_ordered_valid && m) {
+            // the product path tracks the walked prefix of every tile in tile_ordered; for the caller the positions behind
+            // it are filled with padding ids (what the backward treats them as)
+            DeviceGuard dev_guard;
+            HIP_TRY(dev_guard.set(h->device));
+            gut::launch_mask_unordered(h->fwd_stream, (uint32_t)h->tiles, h->ranges.as<uint32_t>(), h->tile_ordered.as<uint32_t>(),
+                                       h->ids_ordered.as<uint32_t>());
+            HIP_TRY(hipStreamSynchronize(h->fwd_stream));
+            h->dbg_ordered_valid = true;
+        }
         *d_ptr = h->lazy_order ? h->ids_ordered.p : h->ids_sorted.p; *bytes = 4 * m; break;
     case GUT_BUF_TILE_RANGES: *d_ptr = h->ranges.p; *bytes = 8 * t; break;
     case GUT_BUF_GRAD_SCRATCH:

@@ -60,36 +60,46 @@ void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, u
                     Counters* counters);
 void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* offset,
                    const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
-                   uint64_t* keys, uint32_t* ids);
+                   uint64_t* keys, uint32_t* ids, uint32_t capacity);
+void launch_pad_keys(hipStream_t s, const uint32_t* count, uint32_t sort_n, uint64_t* keys, uint32_t* ids);
+// debug view only: ordered_ids[range.x + tile_ordered[t] .. range.y) := padding id for every tile t
+void launch_mask_unordered(hipStream_t s, uint32_t tiles, const uint32_t* ranges, const uint32_t* tile_ordered, uint32_t* ordered_ids);
 void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, uint32_t* ranges);
 void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
-                        const uint32_t* tiles_count, const float* feat, const float* grad16,
+                        const uint32_t* tiles_count, const float* feat, float* grad16 /* rows read are left zero */,
                         float* density_grad12, float* sph_grad48, bool raw_grads);
 
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
-                   const uint32_t* sorted_ids, uint32_t num_intersections, float* rgba, float* dist, float* hits,
-                   uint32_t* tile_traversed, const uint64_t* tile_keys /* lazy order only */, uint32_t* ordered_ids /* NULL = list is fully sorted */);
+                   const uint32_t* sorted_ids, const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits,
+                   uint32_t* tile_traversed, const uint64_t* tile_keys /* lazy order only */, uint32_t* ordered_ids /* NULL = list is fully sorted */,
+                   uint32_t* tile_ordered /* lazy order: entries of each tile's list written to ordered_ids */);
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order);
+                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order,
+                       const uint32_t* tile_ordered /* lazy order: valid prefix of each tile's list, else NULL */);
 void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order);
 // sorted (k_buffer_size > 0) compositor variant, gut_render_sorted.hip
 void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
                           const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                          uint32_t num_intersections, float* rgba, float* dist, float* hits);
+                          const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits);
 void launch_render_sorted_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12,
                               const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                               const uint32_t* sorted_ids, const float* rgba, const float* dist, const float* rgba_grad,
                               const float* dist_grad, float* grad16);
 void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density12, const uint32_t* tiles_count,
-                                const float* feat, const float* grad16, float* raw_grad12, float* mrgb);
+                                const float* feat, float* grad16 /* rows read are left zero */, float* raw_grad12, float* mrgb);
 // fused per-Gaussian backward epilogue + SH-gradient + Adam (gut_train.hip), single view, reads the handle's gradient rows
-void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const float* d_camera_position, const float* grad16,
+void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const float* d_camera_position, float* grad16,
                                  const uint32_t* tiles_count, const float* feat, float* raw12, float* raw_m, float* raw_v,
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
-                                 float eps, uint32_t step, const float* visibility, float* act12_out);
+                                 float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only);
+// Adam step of the rows that get no gradient this iteration (tiles_count == 0), see k_adam_rows_without_gradient
+void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t* tiles_count, float* raw12, float* raw_m, float* raw_v,
+                                       float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1,
+                                       float beta2, float eps, uint32_t step, float* act12_out,
+                                       uint32_t block_begin, uint32_t block_end /* range of 256-row blocks */);
 void launch_stats_reduce(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint32_t t, const uint32_t* trav_fwd,
                          const uint32_t* trav_bwd, Counters* out);
 

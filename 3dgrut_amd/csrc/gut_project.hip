@@ -569,7 +569,10 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
                                                         const float2* __restrict__ proj_pos,
                                                         const float4* __restrict__ conic_opacity,
                                                         const float2* __restrict__ extent, const float* __restrict__ depth,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ ids, uint32_t capacity) {
+    // capacity: entries the key / id buffers hold.  The forward sizes them from the previous frames' intersection counts
+    // without waiting for this frame's (gut_api.cpp); should this frame need more, the writes beyond the buffers are dropped
+    // here and the host, which reads the count once everything is queued, grows the buffers and redoes the binning.
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = (int)(threadIdx.x & 63);
     bool active = false;
@@ -586,7 +589,8 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
     if (active) {
         dkey = f2u(depth[i]);
         off = (i == 0) ? 0u : offset[i - 1];
-        max_off = offset[i];
+        max_off = min(offset[i], capacity);
+        off = min(off, max_off);
         p = proj_pos[i];
         bb = tile_bbox(v.grid_x, v.grid_y, p.x, p.y, e.x, e.y);
         area = (bb.x1 - bb.x0) * (bb.y1 - bb.y0);
@@ -597,8 +601,10 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
         if (active)
             for (int y = bb.y0; y < bb.y1; ++y)
                 for (int x = bb.x0; x < bb.x1; ++x) {
-                    keys[off] = ((uint64_t)(uint32_t)(y * v.grid_x + x) << 32) | dkey;
-                    ids[off] = i;
+                    if (off < max_off) {
+                        keys[off] = ((uint64_t)(uint32_t)(y * v.grid_x + x) << 32) | dkey;
+                        ids[off] = i;
+                    }
                     off++;
                 }
         return;
@@ -649,6 +655,36 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
         }
 }
 
+// Padding behind the last real entry: the sort runs over `sort_n` >= M entries (sized on the host before M is known), the tail
+// [M, sort_n) carries the reference's padding pair (gutProjector.cuh:372-376), which sorts behind every tile.
+__global__ __launch_bounds__(kBlock) void k_pad_keys(const uint32_t* __restrict__ count, uint32_t sort_n, uint64_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ ids) {
+    const uint32_t m = *count;
+    for (uint32_t k = m + blockIdx.x * kBlock + threadIdx.x; k < sort_n; k += gridDim.x * kBlock) {
+        keys[k] = ((uint64_t)kInvalid << 32) | f2u(3.4028235e+38f);
+        ids[k] = kInvalid;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask_unordered(uint32_t tiles, const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ tile_ordered, uint32_t* __restrict__ ordered_ids) {
+    const uint32_t t = blockIdx.x;
+    if (t >= tiles) return;
+    const uint2 r = ranges[t];
+    for (uint32_t k = r.x + min(r.y - r.x, tile_ordered[t]) + threadIdx.x; k < r.y; k += kBlock) ordered_ids[k] = kInvalid;
+}
+
+void launch_mask_unordered(hipStream_t s, uint32_t tiles, const uint32_t* ranges, const uint32_t* tile_ordered, uint32_t* ordered_ids) {
+    if (tiles == 0) return;
+    hipLaunchKernelGGL(k_mask_unordered, dim3(tiles), dim3(kBlock), 0, s, tiles, reinterpret_cast<const uint2*>(ranges), tile_ordered,
+                       ordered_ids);
+}
+
+void launch_pad_keys(hipStream_t s, const uint32_t* count, uint32_t sort_n, uint64_t* keys, uint32_t* ids) {
+    if (sort_n == 0) return;
+    hipLaunchKernelGGL(k_pad_keys, dim3(64), dim3(kBlock), 0, s, count, sort_n, keys, ids);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // K5: ranges[tile] = (first, last+1) over the sorted keys; ranges pre-zeroed by the caller
 // ---------------------------------------------------------------------------------------------------
@@ -682,7 +718,7 @@ template <bool kRawGrads>
 __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint32_t n, int sh_degree,
                                                             const float4* __restrict__ density12,
                                                             const uint32_t* __restrict__ tiles_count,
-                                                            const float* __restrict__ feat, const float4* __restrict__ grad16,
+                                                            const float* __restrict__ feat, float4* __restrict__ grad16,
                                                             float4* __restrict__ density_grad12,
                                                             float4* __restrict__ sph_grad48) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -696,6 +732,11 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
         g1 = grad16[4 * (size_t)i + 1];
         g2 = grad16[4 * (size_t)i + 2];
         const float4 g3 = grad16[4 * (size_t)i + 3];
+        // the row is consumed: leave it zero for the next backward (no 64 N-byte clear per step)
+        grad16[4 * (size_t)i + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grad16[4 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grad16[4 * (size_t)i + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grad16[4 * (size_t)i + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float dr = g2.w, dg = g3.x, db = g3.y;
         g2.w = 0.0f;
         const float4 a = density12[3 * (size_t)i];
@@ -742,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
 __global__ __launch_bounds__(kBlock) void k_project_backward_compact(uint32_t n, const float4* __restrict__ density12,
                                                                     const uint32_t* __restrict__ tiles_count,
                                                                     const float* __restrict__ feat,
-                                                                    const float4* __restrict__ grad16,
+                                                                    float4* __restrict__ grad16,
                                                                     float4* __restrict__ raw_grad12, float* __restrict__ mrgb) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -753,6 +794,11 @@ __global__ __launch_bounds__(kBlock) void k_project_backward_compact(uint32_t n,
         g1 = grad16[4 * (size_t)i + 1];
         g2 = grad16[4 * (size_t)i + 2];
         const float4 g3 = grad16[4 * (size_t)i + 3];
+        // the row is consumed: leave it zero for the next backward (no 64 N-byte clear per step)
+        grad16[4 * (size_t)i + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grad16[4 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grad16[4 * (size_t)i + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grad16[4 * (size_t)i + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
         m0 = feat[3 * (size_t)i + 0] > 0.0f ? g2.w : 0.0f;
         m1 = feat[3 * (size_t)i + 1] > 0.0f ? g3.x : 0.0f;
         m2 = feat[3 * (size_t)i + 2] > 0.0f ? g3.y : 0.0f;
@@ -775,10 +821,10 @@ __global__ __launch_bounds__(kBlock) void k_project_backward_compact(uint32_t n,
 }
 
 void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density12, const uint32_t* tiles_count, const float* feat,
-                                const float* grad16, float* raw_grad12, float* mrgb) {
+                                float* grad16, float* raw_grad12, float* mrgb) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_project_backward_compact, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n,
-                       reinterpret_cast<const float4*>(density12), tiles_count, feat, reinterpret_cast<const float4*>(grad16),
+                       reinterpret_cast<const float4*>(density12), tiles_count, feat, reinterpret_cast<float4*>(grad16),
                        reinterpret_cast<float4*>(raw_grad12), mrgb);
 }
 
@@ -837,11 +883,11 @@ void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, u
 
 void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* offset,
                    const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
-                   uint64_t* keys, uint32_t* ids) {
+                   uint64_t* keys, uint32_t* ids, uint32_t capacity) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_expand_tiles, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, offset,
                        reinterpret_cast<const float2*>(proj_pos), reinterpret_cast<const float4*>(conic_opacity),
-                       reinterpret_cast<const float2*>(extent), depth, keys, ids);
+                       reinterpret_cast<const float2*>(extent), depth, keys, ids, capacity);
 }
 
 void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, uint32_t* ranges) {
@@ -851,13 +897,13 @@ void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, 
 }
 
 void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
-                        const uint32_t* tiles_count, const float* feat, const float* grad16, float* density_grad12,
+                        const uint32_t* tiles_count, const float* feat, float* grad16, float* density_grad12,
                         float* sph_grad48, bool raw_grads) {
     if (n == 0) return;
     auto kern = raw_grads ? k_project_backward<true> : k_project_backward<false>;
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), tiles_count, feat,
-                       reinterpret_cast<const float4*>(grad16), reinterpret_cast<float4*>(density_grad12),
+                       reinterpret_cast<float4*>(grad16), reinterpret_cast<float4*>(density_grad12),
                        reinterpret_cast<float4*>(sph_grad48));
 }
 

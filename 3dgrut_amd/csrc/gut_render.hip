@@ -68,10 +68,12 @@ template <bool kLazy>
 __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts c, const float4* __restrict__ density12,
                                                      const float* __restrict__ feat, const float* __restrict__ ray_ori,
                                                      const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
-                                                     const uint32_t* __restrict__ sorted_ids, uint32_t num_intersections,
+                                                     const uint32_t* __restrict__ sorted_ids,
+                                                     const uint32_t* __restrict__ d_num_intersections,
                                                      float4* __restrict__ rgba, float* __restrict__ dist,
                                                      float* __restrict__ hits, uint32_t* __restrict__ tile_traversed,
-                                                     const uint2* __restrict__ tile_keys, uint32_t* __restrict__ ordered_ids) {
+                                                     const uint2* __restrict__ tile_keys, uint32_t* __restrict__ ordered_ids,
+                                                     uint32_t* __restrict__ tile_ordered) {
     __shared__ FwdEntry stage[kBlock];
     __shared__ uint32_t s_deepest, s_first_invalid;
     __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (16x4 strips) can hit it at all
@@ -86,7 +88,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     const bool inside = (px < v.width) && (py < v.height);
     const size_t pix = (size_t)py * (size_t)v.width + (size_t)px;
     // zero intersections: the reference returns before rendering and the outputs keep their initial values
-    // (gutRenderer.cu:323-325); treating every ray as invalid writes exactly those
+    // (gutRenderer.cu:323-325); treating every ray as invalid writes exactly those.  The count is read on the device: the
+    // host queues this launch before it knows it.
+    const uint32_t num_intersections = *d_num_intersections;
     const RayState ray = make_ray(v, ray_ori, ray_dir, pix, inside && (num_intersections != 0));
 
     if (tid == 0) {
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     const uint32_t total = range.y - range.x;
     bool alive = ray.valid;
     float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dsum = 0.f;
-    uint32_t nhits = 0, consumed = 0;
+    uint32_t nhits = 0, consumed = 0, ordered = 0;  // ordered: entries of the list written to ordered_ids (block-uniform)
     bool have_lo = false;           // kLazy: the last list entry ordered so far (block-uniform)
     uint32_t lo_d = 0, lo_p = 0, batch_n = 0, batch_used = 0;
 
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                     ordered_ids[k] = id;
                 }
                 batch_used += take;
+                ordered = base + take;
             } else if (k < range.y) {
                 id = sorted_ids[k];
             }
@@ -258,7 +263,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     // traversal statistics (E_f of the roofline model): deepest list position any pixel of the tile consumed
     atomicMax(&s_deepest, consumed);
     __syncthreads();
-    if (tid == 0) tile_traversed[tile] = s_deepest;
+    if (tid == 0) {
+        tile_traversed[tile] = s_deepest;
+        if (kLazy) tile_ordered[tile] = ordered;  // the backward reads ordered_ids[range.x .. range.x + ordered) only
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -372,7 +380,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
                                                            const float4* __restrict__ rgba_grad,
                                                            const float* __restrict__ dist_grad, float* __restrict__ grad16,
                                                            uint32_t* __restrict__ tile_traversed,
-                                                           const uint32_t* __restrict__ tile_order) {
+                                                           const uint32_t* __restrict__ tile_order,
+                                                           const uint32_t* __restrict__ tile_ordered) {
     constexpr int W = AccLayout<kDistGrad>::kW;
     __shared__ FwdEntry stage[kBlock];
     __shared__ float acc[kBlock * W];
@@ -420,7 +429,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
     const float rdx = usable ? ray.dx : 0.0f, rdy = usable ? ray.dy : 0.0f, rdz = usable ? ray.dz : 1.0f;
     const float rex = usable ? ray.ex : 0.0f, rey = usable ? ray.ey : 0.0f, rez = usable ? ray.ez : 0.0f;
 
-    const uint2 range = ranges[tile];
+    uint2 range = ranges[tile];
+    // lazy order: sorted_ids is the forward's ordered-id list, valid for the prefix of the tile's list the forward staged;
+    // behind it the list ends, exactly as at a padding id
+    if (tile_ordered) range.y = range.x + min(range.y - range.x, tile_ordered[tile]);
     const uint32_t total = range.y - range.x;
     const uint32_t my_slot = reduce_slot(lane);
     bool alive = ray.valid && usable;
@@ -684,15 +696,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
 // ---------------------------------------------------------------------------------------------------
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                   uint32_t num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed,
-                   const uint64_t* tile_keys, uint32_t* ordered_ids) {
+                   const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed,
+                   const uint64_t* tile_keys, uint32_t* ordered_ids, uint32_t* tile_ordered) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     auto kern = ordered_ids != nullptr ? k_render<true> : k_render<false>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12), feat,
-                       ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, num_intersections,
+                       ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, d_num_intersections,
                        reinterpret_cast<float4*>(rgba), dist, hits, tile_traversed, reinterpret_cast<const uint2*>(tile_keys),
-                       ordered_ids);
+                       ordered_ids, tile_ordered);
 }
 
 // Launch order for the backward: tiles by decreasing forward traversal depth (the backward walks exactly as deep),
@@ -732,14 +744,14 @@ void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed,
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order) {
+                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order, const uint32_t* tile_ordered) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     auto kern = dist_grad != nullptr ? k_render_backward<true> : k_render_backward<false>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
                        reinterpret_cast<const float4*>(rgba), reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
-                       tile_traversed, tile_order);
+                       tile_traversed, tile_order, tile_ordered);
 }
 
 }  // namespace gut

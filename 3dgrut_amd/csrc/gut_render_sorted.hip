@@ -99,7 +99,7 @@ __device__ __forceinline__ bool eval_entry(const RenderConsts& c, const RayState
 __global__ __launch_bounds__(kBlock) void k_render_sorted(ViewParams v, RenderConsts c, int K, const float4* __restrict__ density12,
                                                          const float* __restrict__ feat, const float* __restrict__ ray_ori,
                                                          const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
-                                                         const uint32_t* __restrict__ sorted_ids, uint32_t num_intersections,
+                                                         const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ d_num_intersections,
                                                          float4* __restrict__ rgba, float* __restrict__ dist,
                                                          float* __restrict__ hits) {
     __shared__ FwdEntry stage[kBlock];
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted(ViewParams v, RenderCo
     const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + (int)(tid >> 4);
     const bool inside = (px < v.width) && (py < v.height);
     const size_t pix = (size_t)py * (size_t)v.width + (size_t)px;
+    const uint32_t num_intersections = *d_num_intersections;  // read on the device: the host queues this launch before it knows it
     const RayState ray = make_ray(v, ray_ori, ray_dir, pix, inside && (num_intersections != 0));
     const bool centred = __syncthreads_and(ray.centred ? 1 : 0) != 0;
     const uint2 range = ranges[tile];
@@ -376,11 +377,11 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted_backward(ViewParams v,
 
 void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
                           const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                          uint32_t num_intersections, float* rgba, float* dist, float* hits) {
+                          const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     hipLaunchKernelGGL(k_render_sorted, dim3(tiles), dim3(kBlock), 0, s, v, c, K, reinterpret_cast<const float4*>(density12), feat,
-                       ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, num_intersections,
+                       ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, d_num_intersections,
                        reinterpret_cast<float4*>(rgba), dist, hits);
 }
 

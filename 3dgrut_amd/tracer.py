@@ -281,6 +281,18 @@ class SplatRaster:
                                                   None if act_out is None else act_out.data_ptr())
         _capi.check(rc, "optimize_after_bwd")
 
+    def optimize_rows_without_gradient(self, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps, step, act_out=None):
+        """Adam step of the rows the projection gave no tile, on the handle's low-priority side stream, between trace and
+        trace_bwd(..., skip_epilogue=True) (gut_optimize_rows_without_gradient); optimize_after_bwd must follow."""
+        f32p = C.POINTER(C.c_float)
+        stream = torch.cuda.current_stream(raw12.device).cuda_stream
+        with torch.cuda.device(raw12.device):
+            rc = self._lib.gut_optimize_rows_without_gradient(
+                self._handle, C.c_void_p(stream), raw12.data_ptr(), raw_m.data_ptr(), raw_v.data_ptr(), sh48.data_ptr(),
+                sh_m.data_ptr(), sh_v.data_ptr(), lr12.ctypes.data_as(f32p), lr48.ctypes.data_as(f32p), betas[0], betas[1], eps,
+                int(step), None if act_out is None else act_out.data_ptr())
+        _capi.check(rc, "optimize_rows_without_gradient")
+
     def collect_times(self):
         f, b = C.c_float(-1.0), C.c_float(-1.0)
         _capi.check(self._lib.gut_collect_times(self._handle, C.byref(f), C.byref(b)), "collect_times")

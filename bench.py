@@ -63,6 +63,11 @@ def algorithmic_bytes(st, kernel, end_bit):
         # one-pass optimiser (k_sh_adam<scratch>): raw p/m/v in+out 288, next activation 48, SH p/m/v in+out 1152, count 4 per
         # Gaussian; 64-byte gradient row + 12-byte RGB per Gaussian with tiles
         "optimizer": 1492 * N + 76 * V,
+        # split form (default at one view): the rows without tiles (N - V) are updated by k_adam_rows_without_gradient on a side
+        # stream under the compositing kernels, k_sh_adam then walks the V rows with tiles; both read every tile count (4 N)
+        # and the late pass the position row of every Gaussian (16 N, one float4)
+        "optimizer_late": 4 * N + 16 * (N - V) + (1488 + 76) * V,
+        "optimizer_early": 4 * N + 1488 * (N - V),
     }[kernel]
 
 
@@ -201,11 +206,13 @@ def main():
                          "(exercises the N>1 call sequence on a one-GPU box; the number is NOT a bench line)")
     ap.add_argument("--device-pose", dest="host_pose", action="store_false",
                     help="hand the 4x4 camera pose over as a GPU tensor (reference layout; costs one blocking read-back per step)")
-    ap.add_argument("--morton-order", action="store_true",
-                    help="store the Gaussians in Morton (Z-curve) order instead of the scene's random order (NOT the bench line: "
-                         "shows what a spatially coherent parameter layout is worth)")
+    ap.add_argument("--scene-order", action="store_true",
+                    help="native trainer: keep the Gaussians in the order the scene generator emits them (random) instead of the "
+                         "trainer's default storage order along a Morton curve (NativeGaussianModel(spatial_order=True))")
     ap.add_argument("--full-sort", action="store_true", help="switch GUT_OPT_LAZY_TILE_ORDER off (full 44-bit radix sort)")
     ap.add_argument("--selective-adam", action="store_true", help="visibility-masked Adam (reference SelectiveAdam)")
+    ap.add_argument("--no-overlap-optimizer", action="store_true",
+                    help="one optimiser kernel after the backward instead of the early side-stream pass for the rows without tiles")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -249,17 +256,16 @@ def main():
     if args.num_gaussians:
         kw["n"] = args.num_gaussians
     scene = getattr(scenes, fn)(**kw)  # same seed on every rank -> identical replicas
-    if args.morton_order:
-        scene = scenes.reorder(scene, scenes.morton_order(scene["positions"]))
     sh_degree = 3
     tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
     if args.full_sort:
         tracer.tracer_wrapper.set_lazy_tile_order(False)
     if args.trainer == "native":
         native_mod = importlib.import_module("3dgrut_amd.native")
-        model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree)
+        model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree, spatial_order=not args.scene_order)
         stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
-                                             rank=rank, fused_sh_adam=not args.dense_exchange)
+                                             rank=rank, fused_sh_adam=not args.dense_exchange,
+                                             overlap_optimizer=False if args.no_overlap_optimizer else None)
     else:
         model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
         stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
@@ -322,7 +328,9 @@ def main():
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = world * args.steps / elapsed
-        dom = max((k for k in ktimes if ktimes[k] > 0), key=lambda k: ktimes[k])
+        split = ktimes.get("optimizer_early", -1.0) > 0
+        bkey = lambda k: "optimizer_late" if (k == "optimizer" and split) else k   # byte model of the kernel as launched
+        dom = max((k for k in ktimes if ktimes[k] > 0 and k != "optimizer_early"), key=lambda k: ktimes[k])  # on the step's critical path
         # achievable HBM bandwidth of THIS box, for context next to the 8 TB/s spec: device-to-device copy of 2 GB
         a = torch.empty(1 << 29, dtype=torch.float32, device=dev); b = torch.empty_like(a)
         b.copy_(a)
@@ -333,7 +341,7 @@ def main():
         e1.record(); torch.cuda.synchronize(dev)
         copy_gbs = 4 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
-        abytes = algorithmic_bytes(stats, dom, stats["sort_end_bit"])
+        abytes = algorithmic_bytes(stats, bkey(dom), stats["sort_end_bit"])
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
         traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same workload only)
         try:
@@ -345,7 +353,7 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
                     "mean_launch_ms": ktimes[dom], "launches_averaged": kcount, "box_copy_GBps": copy_gbs}
-        per_kernel = {k: {"ms": ktimes[k], "GBps": (algorithmic_bytes(stats, k, stats["sort_end_bit"]) / (ktimes[k] * 1e-3) / 1e9) if ktimes[k] > 0 else None}
+        per_kernel = {k: {"ms": ktimes[k], "GBps": (algorithmic_bytes(stats, bkey(k), stats["sort_end_bit"]) / (ktimes[k] * 1e-3) / 1e9) if ktimes[k] > 0 else None}
                       for k in ktimes}
         out = {
             "metric": "train-step images/sec + render ms/frame, MipNeRF360 bicycle @1/2/4/8 GPU",
@@ -357,7 +365,9 @@ def main():
                        "loss": "0.8*L1+0.2*(1-SSIM) (HIP fused SSIM)",
                        "optimizer": (("HIP fused SH-gradient+Adam" if not args.dense_exchange else "HIP fused Adam") if args.trainer == "native" else "torch.optim.Adam(fused)") +
                                     (" selective(visibility)" if args.selective_adam else "") + ", all 59 params/Gaussian",
-                       "trainer": args.trainer},
+                       "trainer": args.trainer,
+                       "storage_order": ("morton" if (args.trainer == "native" and not args.scene_order) else "as generated"),
+                       "optimizer_overlap": bool(getattr(stepper, "overlap_optimizer", False))},
             "render_ms_per_frame": render_ms,
             "forward_render_ms_in_train": fb.get("forward_render"), "backward_render_ms_in_train": fb.get("backward_render"),
             "phase_ms": phases, "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,

@@ -87,7 +87,8 @@ typedef struct GutStats {
     uint64_t traversed_fwd;      /* E_f : sum over tiles of list entries fetched before the tile terminated */
     uint64_t traversed_bwd;      /* E_b */
     uint32_t sort_end_bit;       /* 32 + bit_width(T) */
-    uint32_t reserved;
+    uint32_t binning_overflows;  /* forwards of this handle whose binning was redone because the frame had more intersections than
+                                    the capacity assumed from earlier frames (the forward is queued before the count is known) */
 } GutStats;
 
 /* intermediate buffers exposed to the parity tests (device pointers into handle scratch, valid until
@@ -188,8 +189,8 @@ int gut_set_option(gut_handle h, int32_t option, int32_t value);
 
 /* per-kernel hipEvent timings of the last trace / trace_bwd (ms), for bench.py's roofline block.
  * Order: project, scan, expand, sort, ranges, render, render_bwd, project_bwd, optimizer (gut_optimize_after_bwd; -1 when
- * that call was not used).  Requires enable_kernel_timings; synchronises. */
-#define GUT_NUM_KERNEL_TIMERS 9
+ * that call was not used), optimizer_early (gut_optimize_rows_without_gradient, timed on its side stream; -1 when not used).  Requires enable_kernel_timings; synchronises. */
+#define GUT_NUM_KERNEL_TIMERS 10
 int gut_kernel_times(gut_handle h, float* ms8);
 /* mean per-kernel time over the (at most 64 most recent) trace/trace_bwd calls since the previous call of this
  * function; *count = number of forward calls averaged.  Synchronises. */
@@ -256,6 +257,19 @@ int gut_optimize_after_bwd(gut_handle h, void* stream, int32_t num_active_featur
                            float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
                            const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
                            const float* d_visibility, float* d_act12_out);
+
+/* Optional first half of that optimiser step, to be called BETWEEN gut_trace and gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) on
+ * the forward's stream: the Gaussians the projection gave no tile (tiles_count == 0) receive an all-zero gradient whatever the
+ * backward computes, so their Adam step (same arithmetic as gut_optimize_after_bwd: moments decay, parameters move on their
+ * momentum, activation rows rewritten) is issued right away on a low-priority side stream owned by the handle, ordered behind
+ * the projection kernel only.  It is pure HBM streaming and runs UNDER the VALU-bound compositing kernels of the same iteration;
+ * the following gut_optimize_after_bwd (mandatory; same pointers and hyper-parameters; d_visibility must be NULL) then only
+ * walks the rows that have tiles and orders the caller's stream behind the side stream.  The parameters after the two calls
+ * are bit-identical to gut_optimize_after_bwd alone.  The caller must not touch the parameter tensors on other streams
+ * between the two calls. */
+int gut_optimize_rows_without_gradient(gut_handle h, void* stream, float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48,
+                                       float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1,
+                                       float beta2, float eps, uint32_t step, float* d_act12_out);
 
 /* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */

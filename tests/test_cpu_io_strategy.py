@@ -188,3 +188,12 @@ def test_morton_order_is_a_locality_preserving_permutation():
     assert d_sorted < 0.25 * d_random
     sc = scenes.reorder(scenes.scene_c1(100, 0), scenes.morton_order(scenes.scene_c1(100, 0)["positions"]))
     assert sc["features"].shape == (100, 48)
+
+
+def test_spatial_permutation_matches_the_numpy_morton_order():
+    import torch
+    native = importlib.import_module("3dgrut_amd.native")
+    pts = np.random.default_rng(3).uniform(-5, 7, size=(5000, 3)).astype(np.float32)
+    perm = native.spatial_permutation(torch.as_tensor(pts)).numpy()
+    assert np.array_equal(perm, scenes.morton_order(pts))
+    assert np.array_equal(np.sort(perm), np.arange(5000))

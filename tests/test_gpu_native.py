@@ -177,3 +177,114 @@ def test_colmap_scene_trains_end_to_end(tmp_path):
         if it >= 30 - len(batches):
             last = float(loss) if last is None else last + float(loss)
     assert last < 0.8 * first, (first, last)
+
+
+def _native_pair(n=20000, seed=21, **kw):
+    sc = scenes.scene_c1(n, seed)
+    steppers = []
+    for overlap in (False, True):
+        model = native.NativeGaussianModel(sc, device=DEV)
+        tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
+        steppers.append(native.NativeTrainStep(model, tracer, scene_extent=1.0, overlap_optimizer=overlap, **kw))
+    return sc, steppers
+
+
+def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
+    """gut_optimize_rows_without_gradient (rows without tiles, side stream, under the compositing kernels) followed by
+    gut_optimize_after_bwd (rows with tiles) leaves EXACTLY the parameters, moments and activations of the one-pass kernel,
+    over several steps with changing views (so rows change sides between steps)."""
+    sc, (ref, ovl) = _native_pair()
+    W, H = 160, 120
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand((1, H, W, 3), generator=g).to(DEV)
+    # cameras INSIDE the cloud looking in different directions: every view sees a different subset of the Gaussians
+    dirs = [(1, 0, 0), (-1, 0.2, 0), (0, 1, 0.1), (0.1, -1, 0), (0, 0.1, 1)]
+    views = [make_view("pinhole", W, H, cams.look_at_c2w((0.05 * k, 0.0, 0.02 * k), d), fx=140.0) for k, d in enumerate(dirs)]
+    some_without_tiles = 0
+    state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48, act=st.act)
+    for k, view in enumerate(views):
+        # both start every step from the same bits (the rows WITH tiles pick up run-to-run differences in the last bits from
+        # the float atomics of the compositing backward, whichever optimiser form follows)
+        for name, t in state(ovl).items():
+            t.copy_(state(ref)[name])
+        for st in (ref, ovl):
+            b = to_batch(view, DEV)
+            b.T_to_world = b.T_to_world.cpu()
+            b.rgb_gt = gt
+            st.step(b)
+        cnt = ovl.raster.debug_buffer("tiles_count")
+        assert torch.equal(cnt, ref.raster.debug_buffer("tiles_count"))
+        early = cnt == 0
+        some_without_tiles += int(early.sum())
+        for name, t in state(ovl).items():
+            r = state(ref)[name]
+            assert torch.equal(r[early], t[early]), f"step {k}: {name} (rows without tiles)"
+            assert torch.allclose(r[~early], t[~early], rtol=2e-5, atol=1e-7), f"step {k}: {name} (rows with tiles)"
+        # rows that had a gradient earlier and have no tiles now keep moving on their momentum (dense Adam semantics)
+        if k > 0:
+            coasting = early & ever_tiles
+            assert int(coasting.sum()) > 0
+            assert float((state(ovl)["raw"][coasting] - before[coasting]).abs().max()) > 0
+        ever_tiles = (~early) if k == 0 else (ever_tiles | ~early)
+        before = state(ovl)["raw"].clone()
+    assert some_without_tiles > 1000
+    kt = ovl.raster.kernel_times()
+    assert kt["optimizer_early"] > 0 and kt["optimizer"] > 0 and ref.raster.kernel_times()["optimizer_early"] < 0
+
+
+def test_half_applied_optimiser_step_is_an_error():
+    sc, (_, ovl) = _native_pair(n=500)
+    view = make_view("pinhole", 64, 48, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64.0)
+    b = to_batch(view, DEV)
+    ovl.forward(b)
+    m = ovl.model
+    args = (m.raw, ovl.m12, ovl.v12, m.features, ovl.m48, ovl.v48, ovl.lr12, ovl.lr48, ovl.betas, ovl.eps, 1, ovl.act)
+    ovl.raster.optimize_rows_without_gradient(*args)
+    with pytest.raises(RuntimeError, match="already called"):
+        ovl.raster.optimize_rows_without_gradient(*args)
+    with pytest.raises(RuntimeError, match="half applied"):
+        ovl.forward(b)
+
+
+def test_spatial_storage_order_is_transparent():
+    """NativeGaussianModel(spatial_order=True) only permutes the rows: same image, and after two train steps the parameters
+    are those of the scene-order model, row for row through `permutation` (up to the float-atomic noise of the backward);
+    restore_spatial_order() after an in-place change keeps the optimiser state attached to its rows."""
+    sc = scenes.scene_c1(6000, 17)
+    W, H = 128, 96
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.3, 0.1, -3.5), (0, 0, 0)), fx=120.0)
+    g = torch.Generator().manual_seed(2)
+    gt = torch.rand((1, H, W, 3), generator=g).to(DEV)
+    steppers = []
+    for spatial in (False, True):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=spatial)
+        steppers.append(native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0))
+    a, b = steppers
+    assert a.model.permutation is None and not a.overlap_optimizer and b.overlap_optimizer
+    perm = b.model.permutation
+    assert torch.equal(a.model.raw[perm], b.model.raw)
+    imgs = []
+    for st in steppers:
+        bt = to_batch(view, DEV); bt.T_to_world = bt.T_to_world.cpu(); bt.rgb_gt = gt
+        rgba, _, _, _ = st.forward(bt)
+        imgs.append(rgba.clone())
+    assert float((imgs[0] - imgs[1]).abs().max()) <= 2e-5
+    # forward() left each handle with a cached forward; run two complete steps
+    for _ in range(2):
+        for st in steppers:
+            bt = to_batch(view, DEV); bt.T_to_world = bt.T_to_world.cpu(); bt.rgb_gt = gt
+            st.step(bt)
+    perm = b.model.permutation
+    assert torch.allclose(a.model.raw[perm], b.model.raw, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(a.model.features[perm], b.model.features, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(a.m48[perm], b.m48, rtol=1e-4, atol=1e-9)
+    # move some Gaussians, re-sort: rows and their moments travel together
+    with torch.no_grad():
+        b.model.raw[:100, 0:3] += 3.0
+    tag = b.model.raw[:, 3].clone(); m_tag = b.m12[:, 3].clone(); old_perm = b.model.permutation.clone()
+    b.restore_spatial_order()
+    new_from_old = torch.argsort(old_perm)[b.model.permutation]   # stored row i now holds what was stored row new_from_old[i]
+    assert torch.equal(b.model.raw[:, 3], tag[new_from_old]) and torch.equal(b.m12[:, 3], m_tag[new_from_old])
+    bt = to_batch(view, DEV); bt.T_to_world = bt.T_to_world.cpu(); bt.rgb_gt = gt
+    loss, _ = b.step(bt)
+    assert np.isfinite(float(loss))

@@ -419,3 +419,38 @@ def test_lazy_tile_order_is_equivalent(name):
     _check_ordered_ids(rb, ref)
     for k, g in ga.items():
         assert rel_l2(getattr(model, k).grad.cpu().numpy(), g.cpu().numpy()) <= 1e-5, k
+
+
+def test_forward_queued_before_the_count_is_known_overflow_and_padding():
+    """The forward sizes its binning buffers from earlier frames and queues everything before this frame's intersection
+    count has been read back (gut_api.cpp).  Frame 1 on a handle has nothing to size from (blocking path); a later frame
+    with FEWER intersections runs over a padded list; one with MORE overflows the capacity and is transparently redone.
+    All three must give the oracle's integer buffers and image."""
+    sc = scenes.scene_c1(3000, 31)
+    model, d12, sph = _oracle_inputs(sc, 3)
+    tr = gut.Tracer({"render": {}})
+    raster = tr.tracer_wrapper
+    W, H = 128, 96
+    cams_ = [((0, 0, -6.0), 110.0),    # frame 1: medium
+             ((0, 0, -14.0), 110.0),   # far away: fewer intersections than the capacity (padded tail)
+             ((0, 0, -2.2), 110.0),    # close: many more than the capacity -> overflow, binning redone
+             ((0, 0, -14.0), 110.0)]   # and back again
+    counts, overflows = [], []
+    for eye, fx in cams_:
+        view = make_view("pinhole", W, H, cams.look_at_c2w(eye, (0, 0, 0)), fx=fx)
+        ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+        out = tr.render(model, to_batch(view, DEV), train=False)
+        st = raster.stats()
+        counts.append(st["num_intersections"]); overflows.append(st["binning_overflows"])
+        assert st["num_intersections"] == ref["M"]
+        for key in ("tiles_count", "tiles_offset", "unsorted_ids", "sorted_ids"):
+            assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
+        for key in ("unsorted_keys", "sorted_keys"):
+            assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint64), ref[key]), key
+        assert np.array_equal(raster.debug_buffer("tile_ranges").cpu().numpy().view(np.uint32).reshape(-1, 2), ref["tile_ranges"])
+        _check_ordered_ids(raster, ref)
+        rgb = out["pred_rgb"][0].detach().cpu().numpy()
+        assert np.abs(rgb - ref["rgba"][..., :3]).max() <= 2e-4
+        assert st["traversed_fwd"] == ref["traversed_fwd"]
+    assert counts[1] < counts[0] < counts[2]
+    assert overflows == [0, 0, 1, 1], (counts, overflows)

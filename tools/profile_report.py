@@ -1,0 +1,137 @@
+"""Dev tool: turn the output of tools/collect_profiles.sh (gpurun_out/profiles) into profiles/<round>/:
+bench_kernel_stats.csv, bench_under_rocprof.json, bench_plain.json, pmc_traffic.json (HBM bytes per launch),
+pmc_sq.json (SQ / TCC / GRBM counters per launch + derived VALU fractions), README.md."""
+import csv, glob, json, os, re, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "profiles")
+rnd = sys.argv[1] if len(sys.argv) > 1 else "round2"
+dst = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+# (regex on the demangled kernel name, bench key).  Templated names: k_render<true>(, k_render_backward<false>(, k_sh_adam<true>(
+KEYS = [(r"\bk_project_on_tiles\b", "project"), (r"\bk_expand_tiles\b", "expand"), (r"\bk_tile_ranges\b", "ranges"),
+        (r"\bk_render(<[^>]*>)?\(", "render"), (r"\bk_render_backward\b", "render_bwd"), (r"\bk_project_backward", "project_bwd"),
+        (r"\bk_sh_adam\b", "optimizer"), (r"\bk_adam_rows\b", "optimizer_early"), (r"onesweep|radix_sort|OneSweep", "sort"),
+        (r"\bk_ssim_|k_photometric", "loss")]
+VALU_ISSUE_NS = 1.16      # one wave64 v_fma_f32 per SIMD every 1.16 ns with >= 2 waves resident (tools/pk_rate.hip, measured)
+SIMDS = 1024
+
+
+def key_of(name):
+    for pat, v in KEYS:
+        if re.search(pat, name):
+            return v
+    return None
+
+
+def counters(pass_name):
+    files = glob.glob(os.path.join(src, "pmc_" + pass_name, "**", "*counter_collection.csv"), recursive=True)
+    acc = {}
+    if not files:
+        return acc
+    for r in csv.DictReader(open(files[0])):
+        k = key_of(r["Kernel_Name"])
+        if k:
+            acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+def kernel_durations(pass_name):
+    files = glob.glob(os.path.join(src, "pmc_" + pass_name, "**", "*kernel_trace.csv"), recursive=True)
+    acc = {}
+    if files:
+        for r in csv.DictReader(open(files[0])):
+            k = key_of(r["Kernel_Name"])
+            if k:
+                acc.setdefault(k, []).append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+shutil.copy(stats[0], os.path.join(dst, "bench_kernel_stats.csv"))
+for f in ("bench_under_rocprof.json", "bench_plain.json"):
+    shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over tools/fwd_once.py 6000000 2 step (two full "
+                   "native train steps, bicycle-like stand-in, 1 MI355X), mean per launch.  FETCH_SIZE/WRITE_SIZE are in KiB.  Per "
+                   "MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half of the bytes of wide (16 B/lane) streaming reads: "
+                   "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.  The factor 2 is calibrated for 16 B/lane streams only; for the "
+                   "gather-heavy kernels (render, render_bwd: 48-byte row gathers) hbm_bytes_uncorrected = (FETCH+WRITE)*1024 is the "
+                   "lower bound and hbm_bytes the upper bound.",
+           "kernels": {}}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, d in counters(ctr).items():
+        if ctr in d:
+            traffic["kernels"].setdefault(k, {})[ctr + "_KiB"] = d[ctr]
+for k, d in traffic["kernels"].items():
+    f, w = d.get("FETCH_SIZE_KiB", 0.0), d.get("WRITE_SIZE_KiB", 0.0)
+    d["hbm_bytes"] = 2 * f * 1024 + w * 1024
+    d["hbm_bytes_uncorrected"] = (f + w) * 1024
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+
+sq = {"note": "separate rocprofv3 --pmc passes (SQ_A, SQ_B, TCC) over tools/fwd_once.py 6000000 2 step, mean per launch, values summed over "
+              "the chip as rocprofv3 reports them.  duration_ms is the kernel-trace duration in the SAME (profiled) pass.  "
+              f"valu_issue_frac = SQ_INSTS_VALU x {VALU_ISSUE_NS} ns / ({SIMDS} SIMDs x duration): share of the chip's measured wave64 VALU "
+              "issue rate (tools/pk_rate.hip) the kernel's vector instructions account for.  valu_active_frac = 4 x SQ_ACTIVE_INST_VALU / "
+              "(4 x SQ_BUSY_CYCLES): SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md, cycle constants).  "
+              "atomic_GBps = TCC_EA0_ATOMIC_sum x 64 B / duration (chip-wide float-atomic rate is about 1300 GB/s).",
+      "kernels": {}}
+for p in ("SQ_A", "SQ_B", "TCC"):
+    dur = kernel_durations(p)
+    for k, d in counters(p).items():
+        e = sq["kernels"].setdefault(k, {})
+        e.update(d)
+        if k in dur:
+            e["duration_ms_" + p] = dur[k]
+for k, e in sq["kernels"].items():
+    if "SQ_INSTS_VALU" in e and "duration_ms_SQ_A" in e:
+        e["valu_issue_frac"] = e["SQ_INSTS_VALU"] * VALU_ISSUE_NS * 1e-9 / (SIMDS * e["duration_ms_SQ_A"] * 1e-3)
+    if e.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in e:
+        e["valu_active_frac"] = e["SQ_ACTIVE_INST_VALU"] / e["SQ_BUSY_CYCLES"]
+    if "TCC_EA0_ATOMIC_sum" in e and "duration_ms_TCC" in e:
+        e["atomic_GBps"] = e["TCC_EA0_ATOMIC_sum"] * 64 / (e["duration_ms_TCC"] * 1e-3) / 1e9
+    if "SQ_WAVE_CYCLES" in e and "SQ_WAIT_ANY" in e:
+        pass
+json.dump(sq, open(os.path.join(dst, "pmc_sq.json"), "w"), indent=1)
+print(json.dumps({k: {c: v for c, v in e.items() if "frac" in c or "GBps" in c or "duration" in c} for k, e in sq["kernels"].items()}, indent=1))
+print(json.dumps(traffic["kernels"], indent=1))
+
+# ---- README.md of the profile directory ----
+rows = list(csv.DictReader(open(os.path.join(dst, "bench_kernel_stats.csv"))))
+plain = json.load(open(os.path.join(dst, "bench_plain.json")))
+prof = json.load(open(os.path.join(dst, "bench_under_rocprof.json")))
+L = ["# Profiles (" + rnd + ")\n",
+     "Collected with `tools/collect_profiles.sh` on one MI355X (gpurun), post-processed by `tools/profile_report.py`.\n",
+     "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5`\n",
+     "Files: `bench_kernel_stats.csv` (rocprofv3 per-kernel summary of that run), `bench_under_rocprof.json` (the bench line printed "
+     "under the profiler), `bench_plain.json` (same command without the profiler, same box), `pmc_traffic.json` (HBM bytes per launch "
+     "from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes), `pmc_sq.json` (SQ / TCC / GRBM counters per launch from three more "
+     "separate `--pmc` passes, with the derived VALU fractions; formulas in its `note`).  All PMC passes run "
+     "`tools/fwd_once.py 6000000 2 step` (two full native train steps of the bench scene).\n",
+     f"Bench line (plain): **{plain['value']:.1f} images/s, {plain['ms_per_step']:.3f} ms/step**, forward render "
+     f"{plain['render_ms_per_frame']:.3f} ms/frame; under the profiler {prof['value']:.1f} images/s.  Phases (HIP events, ms): "
+     + ", ".join(f"{k} {v:.3f}" for k, v in plain["phase_ms"].items()) + ".\n",
+     f"Roofline block of the plain run: dominant kernel `{plain['roofline']['kernel']}`, {plain['roofline']['achieved']:.0f} GB/s of "
+     f"algorithmic bytes = {plain['roofline']['frac']:.2f} of the 8 TB/s spec; a 2 GB device copy on the same box ran at "
+     f"{plain['roofline'].get('box_copy_GBps', float('nan')):.0f} GB/s.\n",
+     "Per-kernel counters (per launch):\n",
+     "| kernel | duration ms (profiled) | HBM bytes (2xFETCH+WRITE) | uncorrected | VALU wave-instr | valu_issue_frac | valu_active_frac | LDS instr | bank-conflict cycles | atomic GB/s |\n|---|---|---|---|---|---|---|---|---|---|"]
+for k in ("project", "expand", "render", "render_bwd", "optimizer", "optimizer_early"):
+    e, t = sq["kernels"].get(k, {}), traffic["kernels"].get(k, {})
+    if not e and not t:
+        continue
+    g = lambda d, c, f="{:.3g}": f.format(d[c]) if c in d else "-"
+    L.append(f"| {k} | {g(e, 'duration_ms_SQ_A', '{:.3f}')} | {g(t, 'hbm_bytes', '{:.3e}')} | {g(t, 'hbm_bytes_uncorrected', '{:.3e}')} | "
+             f"{g(e, 'SQ_INSTS_VALU', '{:.3e}')} | {g(e, 'valu_issue_frac', '{:.2f}')} | {g(e, 'valu_active_frac', '{:.2f}')} | "
+             f"{g(e, 'SQ_INSTS_LDS', '{:.3e}')} | {g(e, 'SQ_LDS_BANK_CONFLICT', '{:.3e}')} | {g(e, 'atomic_GBps', '{:.0f}')} |")
+L += ["", "Top kernels (all launches of the run: 25 train steps + 10 render-only frames + setup):\n",
+      "| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|"]
+for r in rows[:18]:
+    L.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+L.append("")
+dom = [r for r in rows if key_of(r["Name"]) == plain["roofline"]["kernel"]]
+if dom:
+    L.append(f"rocprofv3's average for the dominant kernel (`{dom[0]['Name'][:40]}`: {float(dom[0]['AverageNs']) / 1e3:.1f} us) and the live "
+             f"hipEvent mean in the bench line (`roofline.mean_launch_ms` = {prof['roofline']['mean_launch_ms']:.3f} ms under the profiler, "
+             f"{plain['roofline']['mean_launch_ms']:.3f} ms plain).\n")
+open(os.path.join(dst, "README.md"), "w").write("\n".join(L))
