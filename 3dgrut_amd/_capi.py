@@ -16,6 +16,7 @@ BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
 BWD_SKIP_EPILOGUE = 4
 OPT_LAZY_TILE_ORDER = 1
+OPT_SORTED_REFERENCE_BACKWARD = 2
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer",
                       "optimizer_early")
 

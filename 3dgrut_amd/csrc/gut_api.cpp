@@ -140,6 +140,7 @@ struct gut_context {
     // writes the ids it consumed, in final order, to ids_ordered; the fully sorted lists exist only on debug request
     DevBuf ids_ordered, dbg_keys_sorted, dbg_ids_sorted;
     bool lazy_enabled = true;      // gut_set_option(GUT_OPT_LAZY_TILE_ORDER)
+    bool sorted_reference_bwd = false;  // gut_set_option(GUT_OPT_SORTED_REFERENCE_BACKWARD)
     bool lazy_order = false;       // this forward used the lazy order
     bool dbg_sorted_valid = false;
     // per-T
@@ -678,7 +679,7 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
         gut::launch_render_sorted_bwd(s, v, h->consts, h->cfg.k_buffer_size, d_particle_density, h->feat.as<float>(), d_ray_origin,
                                       d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(),
                                       d_ray_radiance_density, d_ray_hit_distance, d_ray_radiance_density_grad,
-                                      d_ray_hit_distance_grad, h->grad16.as<float>());
+                                      d_ray_hit_distance_grad, h->grad16.as<float>(), h->sorted_reference_bwd);
     } else if (h->m) {
         gut::launch_tile_order(s, (uint32_t)h->tiles, h->trav_fwd.as<uint32_t>(), h->tile_order.as<uint32_t>());
         gut::launch_render_bwd(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
@@ -826,6 +827,7 @@ int gut_set_option(gut_handle h, int32_t option, int32_t value) {
     std::lock_guard<std::mutex> lock(h->mu);
     switch (option) {
     case GUT_OPT_LAZY_TILE_ORDER: h->lazy_enabled = value != 0; return 0;
+    case GUT_OPT_SORTED_REFERENCE_BACKWARD: h->sorted_reference_bwd = value != 0; return 0;
     default: return fail("gut_set_option: unknown option %d", option);
     }
 }

@@ -87,7 +87,7 @@ void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts
 void launch_render_sorted_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12,
                               const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                               const uint32_t* sorted_ids, const float* rgba, const float* dist, const float* rgba_grad,
-                              const float* dist_grad, float* grad16);
+                              const float* dist_grad, float* grad16, bool reference_undo);
 void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density12, const uint32_t* tiles_count,
                                 const float* feat, float* grad16 /* rows read are left zero */, float* raw_grad12, float* mrgb);
 // fused per-Gaussian backward epilogue + SH-gradient + Adam (gut_train.hip), single view, reads the handle's gradient rows

@@ -16,7 +16,8 @@
 //
 // Deviation: the reference's sorted BACKWARD reads the UNclamped precomputed colour while its forward composites
 // max(colour, 0) (gutKBufferRenderer.cuh:130 vs :161); that breaks its own undo recurrence whenever a colour
-// channel is negative.  Here forward and backward both use the clamped colour.
+// channel is negative.  Here forward and backward both use the clamped colour by default;
+// gut_set_option(GUT_OPT_SORTED_REFERENCE_BACKWARD, 1) switches the colour term of d(alpha) to the reference's formula.
 #include "gut_internal.h"
 #include "gut_render_common.h"
 
@@ -190,6 +191,8 @@ struct PixelGrad {
     float T_final, rgbF[3], distF;     // forward results
     float g_rgb[3], g_opacity, g_dist;  // upstream gradients
     float T, rgb_run[3], dist_run;      // running front-to-back state
+    float undo_rgb[3];                  // reference_undo: the reference's "integrated features" state (starts at the final colour)
+    bool reference_undo;                // colour term of d(alpha) exactly as the reference computes it, see backward_hit
 };
 
 // exact derivatives of one composited hit w.r.t. the particle's parameters; 14 atomics into its gradient row
@@ -234,8 +237,25 @@ __device__ void backward_hit(const ViewParams& v, const RenderConsts& c, const R
         b_dist = (pg.distF - pg.dist_run) * iT;
     }
     float g_alpha = pg.g_opacity * pg.T_final / (1.0f - alpha) + pg.g_dist * T * (hit_t - b_dist);
+    if (!pg.reference_undo) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g_alpha += T * pg.g_rgb[k] * (f[k] - b_rgb[k]);
+        for (int k = 0; k < 3; ++k) g_alpha += T * pg.g_rgb[k] * (f[k] - b_rgb[k]);
+    } else {
+        // GUT_OPT_SORTED_REFERENCE_BACKWARD: the reference's sorted backward un-does the back-to-front recurrence
+        // C_k = lerp(C_{k+1}, colour, alpha) from the forward's final colour with the UNCLAMPED precomputed colour
+        // (gutKBufferRenderer.cuh:127-131 hands particleFeatures[idx] to featuresIntegrateBwd, while the forward composited
+        // max(colour, 0), :159-161; recurrence: shRadiativeParticles.slang:179-207 around integrateRadiance<true>, :83-99):
+        //     C_{k+1} = (C_k - colour * alpha) / (1 - alpha),   d(alpha) += (colour - C_{k+1}) . dL/dC_k,  dL/dC_k = T_k dL/dC
+        // With a negative colour channel C_{k+1} is no longer what lies behind the hit, and stays off for every later hit
+        // of the ray.  The feature gradient w * dL/dC and its (colour > 0) mask (K8) are the same in both forms.
+        const float wgt = 1.0f / (1.0f - alpha);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float fu = feat[3 * (size_t)id + k];
+            pg.undo_rgb[k] = (pg.undo_rgb[k] - fu * alpha) * wgt;
+            g_alpha += T * pg.g_rgb[k] * (fu - pg.undo_rgb[k]);
+        }
+    }
     const float g_hit = w * pg.g_dist;
     pg.T = Tn;
 
@@ -305,7 +325,8 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted_backward(ViewParams v,
                                                                   const uint32_t* __restrict__ sorted_ids,
                                                                   const float4* __restrict__ rgba, const float* __restrict__ dist,
                                                                   const float4* __restrict__ rgba_grad,
-                                                                  const float* __restrict__ dist_grad, float* __restrict__ grad16) {
+                                                                  const float* __restrict__ dist_grad, float* __restrict__ grad16,
+                                                                  int reference_undo) {
     __shared__ FwdEntry stage[kBlock];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + (int)(tid & 15);
@@ -321,11 +342,13 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted_backward(ViewParams v,
     PixelGrad pg;
     pg.T_final = 1.f; pg.distF = 0.f; pg.g_opacity = 0.f; pg.g_dist = 0.f; pg.T = 1.0f; pg.dist_run = 0.f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { pg.rgbF[k] = 0.f; pg.g_rgb[k] = 0.f; pg.rgb_run[k] = 0.f; }
+    for (int k = 0; k < 3; ++k) { pg.rgbF[k] = 0.f; pg.g_rgb[k] = 0.f; pg.rgb_run[k] = 0.f; pg.undo_rgb[k] = 0.f; }
+    pg.reference_undo = reference_undo != 0;
     if (ray.valid) {
         const float4 o = rgba[pix], g = rgba_grad[pix];
         pg.T_final = 1.0f - o.w;
         pg.rgbF[0] = o.x; pg.rgbF[1] = o.y; pg.rgbF[2] = o.z;
+        pg.undo_rgb[0] = o.x; pg.undo_rgb[1] = o.y; pg.undo_rgb[2] = o.z;
         pg.distF = dist[pix];
         pg.g_rgb[0] = g.x; pg.g_rgb[1] = g.y; pg.g_rgb[2] = g.z;
         pg.g_opacity = g.w;
@@ -388,12 +411,13 @@ void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts
 void launch_render_sorted_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12,
                               const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                               const uint32_t* sorted_ids, const float* rgba, const float* dist, const float* rgba_grad,
-                              const float* dist_grad, float* grad16) {
+                              const float* dist_grad, float* grad16, bool reference_undo) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     hipLaunchKernelGGL(k_render_sorted_backward, dim3(tiles), dim3(kBlock), 0, s, v, c, K, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
-                       reinterpret_cast<const float4*>(rgba), dist, reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16);
+                       reinterpret_cast<const float4*>(rgba), dist, reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
+                       reference_undo ? 1 : 0);
 }
 
 }  // namespace gut

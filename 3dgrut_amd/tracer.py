@@ -173,6 +173,9 @@ class SplatRaster:
         self.enable_kernel_timings = bool(cfg.enable_kernel_timings)
         _capi.check(self._lib.gut_create(C.byref(cfg), self.device_index, C.byref(self._handle)), "SplatRaster()")
         self._timings = {}
+        # extension key (not in the reference's configs): render.splat.sorted_reference_backward
+        if not isinstance(config, _capi.GutConfig) and bool(_conf_get(config, "render.splat.sorted_reference_backward", False)):
+            self.set_sorted_reference_backward(True)
 
     def __del__(self):
         try:
@@ -306,6 +309,10 @@ class SplatRaster:
     def set_lazy_tile_order(self, on=True):
         """Tile-only radix grouping + per-tile lazy depth order in the forward compositor (default on; gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_LAZY_TILE_ORDER, 1 if on else 0), "set_option")
+
+    def set_sorted_reference_backward(self, on=True):
+        """Sorted variant: the reference's own (unclamped-colour undo) form of the alpha gradient (default off; gut_hip.h)."""
+        _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_SORTED_REFERENCE_BACKWARD, 1 if on else 0), "set_option")
 
     def stats(self):
         s = _capi.GutStats()

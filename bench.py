@@ -40,10 +40,14 @@ WORKLOADS = {
     # BASELINE configs[3]: ScanNet++-DSLR-like OpenCV fisheye (zero radial coefficients, as its loader sets them), camera
     # inside the scene; fx is the fisheye focal length (equidistant model): ~150 degrees across the 1752-pixel width
     "scannetpp_like_fisheye_300k_1752x1168": ("scene_lego_like", dict(n=300_000, seed=3), 1752, 1168, 660.0, 0.6, 10.0, 1.3),
+    # workload sensitivity (not a BASELINE config): the bicycle stand-in with SURVEY.md §8d C3's literal parameters
+    "bicycle_like_6M_survey_c3": ("scene_outdoor_like", dict(n=6_000_000, seed=2, scale_mu=math.log(0.01), opacity_logit_mean=0.0,
+                                                           opacity_logit_std=1.5), 1237, 822, 1040.0, 4.5, 12.0, 5.0),
     # BASELINE configs[4]: MipNeRF360-garden-like, one view per GPU
     "garden_like_5M_1297x840": ("scene_outdoor_like", dict(n=5_000_000, seed=4), 1297, 840, 1090.0, 4.2, 15.0, 5.0),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_ISSUE_NS = 1.16   # one wave64 VALU instruction per SIMD every 1.16 ns with >= 2 waves resident (tools/pk_rate.hip, measured)
 
 
 def algorithmic_bytes(st, kernel, end_bit):
@@ -188,6 +192,116 @@ def self_launch(argv, n_gpus):
     return 0
 
 
+def profile_counters():
+    """Per-kernel PMC counters of the tracked profile of this command (profiles/<latest round>/pmc_traffic.json, pmc_sq.json)."""
+    out = {}
+    for rnd in ("round2", "round1"):
+        d = os.path.join(ROOT, "profiles", rnd)
+        if not os.path.isfile(os.path.join(d, "pmc_traffic.json")):
+            continue
+        try:
+            for k, v in json.load(open(os.path.join(d, "pmc_traffic.json")))["kernels"].items():
+                out.setdefault(k, {}).update(v)
+            if os.path.isfile(os.path.join(d, "pmc_sq.json")):
+                for k, v in json.load(open(os.path.join(d, "pmc_sq.json")))["kernels"].items():
+                    out.setdefault(k, {}).update(v)
+            out["_source"] = f"profiles/{rnd}"
+            return out
+        except Exception:
+            out = {}
+    return out
+
+
+def run_workload(args, env, workload, steps, warmup, render_frames):
+    """Build the workload, run `warmup` untimed and `steps` timed train steps (barrier + synchronize on both sides, max over
+    ranks), then `render_frames` forward-only frames.  Returns the measurements and the objects the report needs."""
+    rank, world, dev, dist = env["rank"], env["world"], env["dev"], env["dist"]
+    gut = importlib.import_module("3dgrut_amd")
+    scenes = importlib.import_module("3dgrut_amd.scenes")
+    cams = importlib.import_module("3dgrut_amd.cameras")
+    pose_mod = importlib.import_module("3dgrut_amd.pose")
+    model_mod = importlib.import_module("3dgrut_amd.model")
+    train_mod = importlib.import_module("3dgrut_amd.train")
+    dp_mod = importlib.import_module("3dgrut_amd.dp")
+
+    fn, kw, W, H, fx, radius, elev, extent = WORKLOADS[workload]
+    kw = dict(kw)
+    if args.num_gaussians:
+        kw["n"] = args.num_gaussians
+    scene = getattr(scenes, fn)(**kw)  # same seed on every rank -> identical replicas
+    sh_degree = 3
+    tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
+    if args.full_sort:
+        tracer.tracer_wrapper.set_lazy_tile_order(False)
+    if args.trainer == "native":
+        native_mod = importlib.import_module("3dgrut_amd.native")
+        model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree, spatial_order=not args.scene_order)
+        stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
+                                             rank=rank, fused_sh_adam=not args.dense_exchange,
+                                             overlap_optimizer=False if args.no_overlap_optimizer else None)
+    else:
+        model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
+        stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
+
+    n_views = max(8, world)
+    fisheye = "fisheye" in workload
+    ro, rd, c2ws = make_views(cams, n_views, W, H, fx, radius, elev, fisheye)
+    ro_t, rd_t = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
+    K = cams.fisheye_intrinsics_dict(W, H, fx, fx) if fisheye else cams.pinhole_intrinsics_dict(W, H, fx, fx)
+    kkey = "intrinsics_OpenCVFisheyeCameraModelParameters" if fisheye else "intrinsics_OpenCVPinholeCameraModelParameters"
+    g = torch.Generator(device="cpu").manual_seed(100)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    gt = torch.stack([0.5 + 0.4 * torch.sin(6.0 * xx), 0.5 + 0.4 * torch.cos(5.0 * yy), 0.5 * (xx + yy)], -1)
+    gt = (gt + 0.02 * torch.randn(gt.shape, generator=g)).clamp(0, 1)[None].to(dev)
+
+    def batch_for(step):
+        v = dp_mod.view_index(step, rank, world, n_views)
+        # the 4x4 pose stays on the host (the tracer needs it there to fill the camera struct; a device tensor would
+        # cost a blocking read-back per step, as in the reference's tracer.py:353-356)
+        pose = torch.as_tensor(c2ws[v])[None] if args.host_pose else torch.as_tensor(c2ws[v], device=dev)[None]
+        return gut.Batch(rays_ori=ro_t, rays_dir=rd_t, T_to_world=pose, rgb_gt=gt, **{kkey: K})
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for s in range(warmup):
+        stepper.step(batch_for(s))
+    raster = tracer.tracer_wrapper
+    barrier()
+    raster.kernel_times_mean()  # reset the per-kernel event ring
+    raster.collect_times()
+    if hasattr(stepper, "phase_timing"):
+        stepper.phase_timing = True
+    t0 = time.perf_counter()
+    for s in range(steps):
+        stepper.step(batch_for(warmup + s))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    phases = stepper.phase_times_mean() if hasattr(stepper, "phase_times_mean") else {}
+    if hasattr(stepper, "phase_timing"):
+        stepper.phase_timing = False
+    ktimes, kcount = raster.kernel_times_mean()
+    fb = raster.collect_times()
+    stats = raster.stats()
+
+    # forward-only render time (reference's FPS definition: mean forward_render ms, threedgrut/render.py:231-251)
+    with torch.no_grad():
+        for s in range(render_frames):
+            stepper.render(batch_for(s), train=False)
+    torch.cuda.synchronize(dev)
+    render_ms = raster.collect_times().get("forward_render", float("nan"))
+    return dict(value=world * steps / elapsed, ms_per_step=1000.0 * elapsed / steps, phases=phases, ktimes=ktimes, kcount=kcount, fb=fb,
+                stats=stats, render_ms=render_ms, scene=scene, cams=cams, pose_mod=pose_mod, c2ws=c2ws, W=W, H=H, fx=fx,
+                fisheye=fisheye, stepper=stepper)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +310,7 @@ def main():
     ap.add_argument("--workload", default="bicycle_like_6M_1237x822", choices=list(WORKLOADS))
     ap.add_argument("--num-gaussians", type=int, default=0, help="override N (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the short second measurement on bicycle_like_6M_survey_c3")
     ap.add_argument("--render-frames", type=int, default=10)
     ap.add_argument("--trainer", default="native", choices=["native", "autograd"],
                     help="native: fused HIP activation/Adam around the renderer; autograd: torch.autograd + torch.optim.Adam")
@@ -243,94 +358,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    gut = importlib.import_module("3dgrut_amd")
-    scenes = importlib.import_module("3dgrut_amd.scenes")
-    cams = importlib.import_module("3dgrut_amd.cameras")
-    pose_mod = importlib.import_module("3dgrut_amd.pose")
-    model_mod = importlib.import_module("3dgrut_amd.model")
-    train_mod = importlib.import_module("3dgrut_amd.train")
-    dp_mod = importlib.import_module("3dgrut_amd.dp")
-
-    fn, kw, W, H, fx, radius, elev, extent = WORKLOADS[args.workload]
-    kw = dict(kw)
-    if args.num_gaussians:
-        kw["n"] = args.num_gaussians
-    scene = getattr(scenes, fn)(**kw)  # same seed on every rank -> identical replicas
-    sh_degree = 3
-    tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
-    if args.full_sort:
-        tracer.tracer_wrapper.set_lazy_tile_order(False)
-    if args.trainer == "native":
-        native_mod = importlib.import_module("3dgrut_amd.native")
-        model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree, spatial_order=not args.scene_order)
-        stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
-                                             rank=rank, fused_sh_adam=not args.dense_exchange,
-                                             overlap_optimizer=False if args.no_overlap_optimizer else None)
-    else:
-        model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
-        stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
-
-    n_views = max(8, world)
-    fisheye = "fisheye" in args.workload
-    ro, rd, c2ws = make_views(cams, n_views, W, H, fx, radius, elev, fisheye)
-    ro_t, rd_t = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
-    K = cams.fisheye_intrinsics_dict(W, H, fx, fx) if fisheye else cams.pinhole_intrinsics_dict(W, H, fx, fx)
-    kkey = "intrinsics_OpenCVFisheyeCameraModelParameters" if fisheye else "intrinsics_OpenCVPinholeCameraModelParameters"
-    g = torch.Generator(device="cpu").manual_seed(100)
-    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
-    gt = torch.stack([0.5 + 0.4 * torch.sin(6.0 * xx), 0.5 + 0.4 * torch.cos(5.0 * yy), 0.5 * (xx + yy)], -1)
-    gt = (gt + 0.02 * torch.randn(gt.shape, generator=g)).clamp(0, 1)[None].to(dev)
-
-    def batch_for(step):
-        v = dp_mod.view_index(step, rank, world, n_views)
-        # the 4x4 pose stays on the host (the tracer needs it there to fill the camera struct; a device tensor would
-        # cost a blocking read-back per step, as in the reference's tracer.py:353-356)
-        pose = torch.as_tensor(c2ws[v])[None] if args.host_pose else torch.as_tensor(c2ws[v], device=dev)[None]
-        return gut.Batch(rays_ori=ro_t, rays_dir=rd_t, T_to_world=pose, rgb_gt=gt, **{kkey: K})
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for s in range(args.warmup):
-        stepper.step(batch_for(s))
-    raster = tracer.tracer_wrapper
-    barrier()
-    raster.kernel_times_mean()  # reset the per-kernel event ring
-    raster.collect_times()
-    if hasattr(stepper, "phase_timing"):
-        stepper.phase_timing = True
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        stepper.step(batch_for(args.warmup + s))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    phases = stepper.phase_times_mean() if hasattr(stepper, "phase_times_mean") else {}
-    if hasattr(stepper, "phase_timing"):
-        stepper.phase_timing = False
-    ktimes, kcount = raster.kernel_times_mean()
-    fb = raster.collect_times()
-    stats = raster.stats()
-
-    # forward-only render time (reference's FPS definition: mean forward_render ms, threedgrut/render.py:231-251)
-    with torch.no_grad():
-        for s in range(args.render_frames):
-            stepper.render(batch_for(s), train=False)
-    torch.cuda.synchronize(dev)
-    render_ms = raster.collect_times().get("forward_render", float("nan"))
+    env = dict(rank=rank, world=world, dev=dev, dist=dist)
+    res = run_workload(args, env, args.workload, args.steps, args.warmup, args.render_frames)
 
     if rank == 0:
-        ms_per_step = 1000.0 * elapsed / args.steps
-        value = world * args.steps / elapsed
+        ktimes, stats, stepper = res["ktimes"], res["stats"], res["stepper"]
+        W, H, fx = res["W"], res["H"], res["fx"]
         split = ktimes.get("optimizer_early", -1.0) > 0
         bkey = lambda k: "optimizer_late" if (k == "optimizer" and split) else k   # byte model of the kernel as launched
-        dom = max((k for k in ktimes if ktimes[k] > 0 and k != "optimizer_early"), key=lambda k: ktimes[k])  # on the step's critical path
+        # dominant kernel = the longest one on the step's critical path (the early optimiser pass runs on a side stream
+        # under the compositing kernels and is reported under per_kernel only)
+        dom = max((k for k in ktimes if ktimes[k] > 0 and k != "optimizer_early"), key=lambda k: ktimes[k])
         # achievable HBM bandwidth of THIS box, for context next to the 8 TB/s spec: device-to-device copy of 2 GB
         a = torch.empty(1 << 29, dtype=torch.float32, device=dev); b = torch.empty_like(a)
         b.copy_(a)
@@ -343,22 +381,36 @@ def main():
         del a, b
         abytes = algorithmic_bytes(stats, bkey(dom), stats["sort_end_bit"])
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, same workload only)
-        try:
-            if args.workload == "bicycle_like_6M_1237x822" and not args.num_gaussians:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1", "pmc_traffic.json")))
-                traffic = pmc["kernels"][dom]["hbm_bytes"]
-        except Exception:
-            traffic = None
+        # PMC counters are NOT collected in this run (rocprofv3 --pmc needs its own passes): they are replayed from the
+        # tracked profile of the same command and workload, and say so
+        prof = profile_counters() if (args.workload == "bicycle_like_6M_1237x822" and not args.num_gaussians
+                                      and args.trainer == "native" and not args.scene_order) else {}
+        pk = lambda k: prof.get("optimizer" if k == "optimizer" else k, {})
+        traffic = pk(dom).get("hbm_bytes")
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
-                    "mean_launch_ms": ktimes[dom], "launches_averaged": kcount, "box_copy_GBps": copy_gbs}
-        per_kernel = {k: {"ms": ktimes[k], "GBps": (algorithmic_bytes(stats, bkey(k), stats["sort_end_bit"]) / (ktimes[k] * 1e-3) / 1e9) if ktimes[k] > 0 else None}
-                      for k in ktimes}
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": (prof.get("_source") + " (separate rocprofv3 --pmc passes of the same workload, replayed here)") if traffic else None,
+                    "algorithmic_bytes": abytes, "mean_launch_ms": ktimes[dom], "launches_averaged": res["kcount"],
+                    "box_copy_GBps": copy_gbs}
+        per_kernel = {}
+        for k in ktimes:
+            e = {"ms": ktimes[k],
+                 "GBps": (algorithmic_bytes(stats, bkey(k), stats["sort_end_bit"]) / (ktimes[k] * 1e-3) / 1e9) if ktimes[k] > 0 else None}
+            c = pk(k)
+            if ktimes[k] > 0 and "SQ_INSTS_VALU" in c:
+                # share of the chip's measured wave64 VALU issue rate (1 instruction / 1.16 ns / SIMD, tools/pk_rate.hip):
+                # profile's VALU wave-instructions per launch / (this run's duration x 1024 SIMDs x that rate)
+                e["valu_frac"] = c["SQ_INSTS_VALU"] * VALU_ISSUE_NS * 1e-9 / (1024 * ktimes[k] * 1e-3)
+                e["valu_wave_instructions"] = c["SQ_INSTS_VALU"]
+                e["counters_source"] = prof.get("_source")
+            if "hbm_bytes" in c:
+                e["traffic"] = c["hbm_bytes"]
+            per_kernel[k] = e
+        sh_degree = 3
         out = {
             "metric": "train-step images/sec + render ms/frame, MipNeRF360 bicycle @1/2/4/8 GPU",
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "num_gaussians": int(stats["num_particles"]), "resolution": [W, H],
                        "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}" + ("" if world == 1 else (" dense all-reduce [N,60]" if (args.dense_exchange or args.trainer != "native") else " all-reduce [N,12] + all-gather [N,3]")),
@@ -368,21 +420,37 @@ def main():
                        "trainer": args.trainer,
                        "storage_order": ("morton" if (args.trainer == "native" and not args.scene_order) else "as generated"),
                        "optimizer_overlap": bool(getattr(stepper, "overlap_optimizer", False))},
-            "render_ms_per_frame": render_ms,
-            "forward_render_ms_in_train": fb.get("forward_render"), "backward_render_ms_in_train": fb.get("backward_render"),
-            "phase_ms": phases, "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
+            "render_ms_per_frame": res["render_ms"],
+            "forward_render_ms_in_train": res["fb"].get("forward_render"), "backward_render_ms_in_train": res["fb"].get("backward_render"),
+            "phase_ms": res["phases"], "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
             "reference_rtx5090": {"images_per_s": 31.6, "render_ms": 3.64, "note": "README.md:320, different hardware, real dataset"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                if fisheye:
+                if res["fisheye"]:
                     raise RuntimeError("the CPU baselines are wired for the pinhole workloads")
-                out["cpu_baseline"] = cpu_baseline(scene, cams, pose_mod, W, H, fx, c2ws[0], sh_degree)
+                out["cpu_baseline"] = cpu_baseline(res["scene"], res["cams"], res["pose_mod"], W, H, fx, res["c2ws"][0], sh_degree)
                 # north_star's wording: a pure-PyTorch per-ray composite on the host cores, same run (second, smaller sample)
-                out["cpu_baseline_per_ray_torch"] = cpu_baseline_per_ray_torch(scene, cams, pose_mod, W, H, fx, c2ws[0], sh_degree)
+                out["cpu_baseline_per_ray_torch"] = cpu_baseline_per_ray_torch(res["scene"], res["cams"], res["pose_mod"], W, H, fx,
+                                                                               res["c2ws"][0], sh_degree)
             except Exception as e:  # the baseline is reported, never a gate
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        # workload sensitivity: the same train step on the denser stand-in with SURVEY §8d C3's literal parameters
+        # (a short, labelled second measurement; `value` above stays the headline workload)
+        if world == 1 and args.workload == "bicycle_like_6M_1237x822" and not args.no_sensitivity and not args.num_gaussians:
+            try:
+                del res, stepper
+                torch.cuda.empty_cache()
+                r2 = run_workload(args, env, "bicycle_like_6M_survey_c3", 10, 3, 5)
+                out["sensitivity"] = {"workload": "bicycle_like_6M_survey_c3",
+                                      "note": "same step on the stand-in generated with SURVEY.md §8d C3's literal parameters (log-normal scales "
+                                              "mu = ln 0.01, opacity logits N(0, 1.5)): larger, more opaque splats, far more tile intersections",
+                                      "value": r2["value"], "unit": "images/s", "ms_per_step": r2["ms_per_step"], "steps": 10, "warmup": 3,
+                                      "render_ms_per_frame": r2["render_ms"], "phase_ms": r2["phases"], "scene_stats": r2["stats"],
+                                      "per_kernel_ms": {k: v for k, v in r2["ktimes"].items()}}
+            except Exception as e:
+                out["sensitivity"] = {"workload": "bicycle_like_6M_survey_c3", "error": f"{type(e).__name__}: {e}"}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

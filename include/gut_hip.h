@@ -185,6 +185,12 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * depths and gradients are identical to the fully sorted path; GUT_BUF_ORDERED_IDS shows what was walked, GUT_BUF_SORTED_*
  * still return the reference's full lists (built on request).  0 restores the full radix sort. */
 #define GUT_OPT_LAZY_TILE_ORDER 1
+/* GUT_OPT_SORTED_REFERENCE_BACKWARD (default 0; sorted variant k_buffer_size > 0 only): compute the colour term of d(alpha) in
+ * the backward exactly as the reference does — un-doing the back-to-front colour recurrence from the final colour with the
+ * UNclamped precomputed colour (gutKBufferRenderer.cuh:127-131, shRadiativeParticles.slang:179-207) although the forward
+ * composited max(colour, 0) (:159-161).  Identical to the default wherever no composited colour channel is negative; where one
+ * is, the reference's gradient is not the derivative of its own forward (the default is).  For like-for-like comparisons. */
+#define GUT_OPT_SORTED_REFERENCE_BACKWARD 2
 int gut_set_option(gut_handle h, int32_t option, int32_t value);
 
 /* per-kernel hipEvent timings of the last trace / trace_bwd (ms), for bench.py's roofline block.

@@ -270,14 +270,56 @@ def render_per_ray(cam, tq, W, H, params, ray_ori, ray_dir, sh_degree=3, dtype=t
     return out[:, :4], out[:, 4], out[:, 5]
 
 
-def composite_ordered(params, tq, W, H, ray_ori, ray_dir, order_ids, order_count, sh_degree=3, dtype=torch.float64):
+class _ReferenceUndoColour(torch.autograd.Function):
+    """rgb = sum_k w_k max(colour_k, 0) with the BACKWARD the reference's sorted variant computes for it
+    (gutKBufferRenderer.cuh:117-137 -> featuresIntegrateBwd, shRadiativeParticles.slang:179-207 around
+    integrateRadiance<true>, :83-99): walking the hits front to back it un-does the back-to-front recurrence
+    C_k = lerp(C_{k+1}, colour_k, alpha_k) from the forward's final colour,
+        C_{k+1} = (C_k - colour_k alpha_k) / (1 - alpha_k),   d alpha_k += (colour_k - C_{k+1}) . G_k,
+        d colour_k = alpha_k G_k,   G_{k+1} = (1 - alpha_k) G_k,   G_1 = dL/d rgb,
+    but with the UNCLAMPED colour particleFeatures[idx] (the forward composited max(colour, 0), :159-161).  The colour
+    gradient then passes the (colour > 0) mask of the SH backward (gaussianParticles.cuh:120-187)."""
+
+    @staticmethod
+    def forward(ctx, alpha, colour_unclamped):   # alpha [P,L] (0 where no hit), colour [P,L,3]
+        one_m = 1 - alpha
+        T_before = torch.cat([torch.ones_like(alpha[:, :1]), torch.cumprod(one_m, dim=1)[:, :-1]], dim=1)
+        rgb = ((alpha * T_before)[..., None] * colour_unclamped.clamp(min=0)).sum(1)
+        ctx.save_for_backward(alpha, colour_unclamped, rgb)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        alpha, col, rgb = ctx.saved_tensors
+        P, L = alpha.shape
+        C = rgb.clone()          # ray.featuresBackward: the forward's final colour
+        G = g_rgb.clone()        # ray.featuresGradient
+        d_alpha = torch.zeros_like(alpha)
+        d_col = torch.zeros_like(col)
+        for k in range(L):
+            a = alpha[:, k]
+            hit = a > 0
+            wgt = torch.where(hit, 1.0 / (1.0 - a), torch.ones_like(a))
+            Cn = torch.where(hit[:, None], (C - col[:, k] * a[:, None]) * wgt[:, None], C)
+            d_alpha[:, k] = torch.where(hit, ((col[:, k] - Cn) * G).sum(-1), torch.zeros_like(a))
+            d_col[:, k] = torch.where(hit[:, None], a[:, None] * G, torch.zeros_like(G)) * (col[:, k] > 0)
+            G = torch.where(hit[:, None], (1.0 - a)[:, None] * G, G)
+            C = Cn
+        return d_alpha, d_col
+
+
+def composite_ordered(params, tq, W, H, ray_ori, ray_dir, order_ids, order_count, sh_degree=3, dtype=torch.float64,
+                      reference_undo_colour=False):
     """Exact (autograd) compositing of each pixel's particles in a GIVEN order — the sorted variant's semantics
     (k_buffer_size > 0): the reference differentiates it with slang autodiff (gaussianParticles.slang:394-451,
     shRadiativeParticles.slang:179-207), i.e. true derivatives incl. min(0.99, .) and the hit distance.
-    order_ids [P,L] (-1 padded) comes from the C oracle.  Returns rgba [P,4], dist [P]."""
+    order_ids [P,L] (-1 padded) comes from the C oracle.  Returns rgba [P,4], dist [P].
+    reference_undo_colour=True: same forward, but the colour's backward is the reference's own un-do recurrence with the
+    unclamped colour (_ReferenceUndoColour) instead of the true derivative."""
     R, t, Rinv, cam_pos = pose_matrices(tq, dtype)
     pos, rot, scl, dns, sph = (params[k].to(dtype) for k in ("positions", "rotation", "scale", "density", "features"))
-    feat_all = precompute_features(pos, sph, cam_pos, sh_degree).clamp(min=0)
+    feat_unclamped = precompute_features(pos, sph, cam_pos, sh_degree)
+    feat_all = feat_unclamped.clamp(min=0)
     rows_all = quat_rows(rot)
     o, d = world_rays(torch.as_tensor(ray_ori, dtype=dtype), torch.as_tensor(ray_dir, dtype=dtype), Rinv, cam_pos)
     ids = torch.as_tensor(order_ids.astype("int64"))
@@ -297,7 +339,10 @@ def composite_ordered(params, tq, W, H, ray_ori, ray_dir, order_ids, order_count
     one_m = 1 - alpha
     T_before = torch.cat([torch.ones(P, 1, dtype=dtype), torch.cumprod(one_m, dim=1)[:, :-1]], dim=1)
     w = alpha * T_before
-    rgb = (w[..., None] * ft).sum(1)
+    if reference_undo_colour:
+        rgb = _ReferenceUndoColour.apply(alpha, feat_unclamped[idc])
+    else:
+        rgb = (w[..., None] * ft).sum(1)
     dist = (w * torch.where(valid, hit_t, torch.zeros_like(hit_t))).sum(1)
     T = one_m.prod(dim=1)
     return torch.cat([rgb, (1 - T)[:, None]], dim=1), dist

@@ -203,3 +203,34 @@ def test_decision_margins_flag_a_response_sitting_on_the_threshold():
     edge = hit & ~(np.roll(hit, 1, 0) & np.roll(hit, -1, 0) & np.roll(hit, 1, 1) & np.roll(hit, -1, 1))
     assert thr[H // 2, W // 2] > 1e4 and np.median(thr[edge]) < np.median(thr[hit & ~edge])
     assert (thr[hit] < 4.0).mean() < 0.05
+
+
+def test_reference_undo_colour_backward_equals_the_true_derivative_without_negative_colours():
+    """oracle/per_ray_torch._ReferenceUndoColour (the reference's sorted-variant colour backward, un-do form): with all colours
+    >= 0 it is the exact derivative of the compositing sum; with a negative channel its alpha gradient is not."""
+    import torch
+    prt = importlib.import_module("oracle.per_ray_torch")
+    g = torch.Generator().manual_seed(0)
+    P, L = 50, 7
+    up = torch.randn(P, 3, generator=g, dtype=torch.float64)
+
+    def both(col0):
+        out = []
+        for ref in (True, False):
+            alpha = (torch.rand(P, L, generator=torch.Generator().manual_seed(1), dtype=torch.float64) * 0.9).requires_grad_(True)
+            col = col0.clone().requires_grad_(True)
+            if ref:
+                rgb = prt._ReferenceUndoColour.apply(alpha, col)
+            else:
+                Tb = torch.cat([torch.ones(P, 1, dtype=torch.float64), torch.cumprod(1 - alpha, 1)[:, :-1]], 1)
+                rgb = ((alpha * Tb)[..., None] * col.clamp(min=0)).sum(1)
+            (rgb * up).sum().backward()
+            out.append((rgb.detach(), alpha.grad, col.grad))
+        return out
+    pos = torch.rand(P, L, 3, generator=g, dtype=torch.float64)
+    (r1, a1, c1), (r2, a2, c2) = both(pos)
+    assert float((r1 - r2).abs().max()) == 0 and float((a1 - a2).abs().max()) < 1e-13 and float((c1 - c2).abs().max()) < 1e-13
+    neg = pos.clone(); neg[:, 2, 0] = -0.7
+    (r1, a1, c1), (r2, a2, c2) = both(neg)
+    assert float((r1 - r2).abs().max()) == 0 and float((c1 - c2).abs().max()) < 1e-13
+    assert float((a1 - a2).abs().max()) > 1e-3

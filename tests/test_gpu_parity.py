@@ -288,8 +288,8 @@ def test_timings_surface():
 # ---------------------------------------------------------------------------------------------------
 # sorted variant (render.splat.k_buffer_size > 0), SURVEY §8a row a14
 # ---------------------------------------------------------------------------------------------------
-def _run_sorted(view, model, K, rgba_grad=None, dist_grad=None):
-    tr = gut.Tracer({"render": {"splat": {"k_buffer_size": K}}})
+def _run_sorted(view, model, K, rgba_grad=None, dist_grad=None, reference_backward=False):
+    tr = gut.Tracer({"render": {"splat": {"k_buffer_size": K, "sorted_reference_backward": reference_backward}}})
     out = tr.render(model, to_batch(view, DEV), train=True, frame_id=0)
     if rgba_grad is not None:
         rg = torch.as_tensor(rgba_grad, device=DEV)
@@ -367,6 +367,52 @@ def test_sorted_variant_backward(name, with_dist_grad):
         g = getattr(model, k).grad.cpu().numpy()
         err = rel_l2(g, e)
         assert err <= 2e-3, f"{name}/{k}: rel L2 {err}"
+
+
+@pytest.mark.parametrize("name", ["c1_pinhole_128", "dense_big_splats"])
+def test_sorted_variant_reference_backward(name):
+    """GUT_OPT_SORTED_REFERENCE_BACKWARD: the reference's own form of the sorted backward (un-do recurrence with the UNCLAMPED
+    colour, gutKBufferRenderer.cuh:127-131 / shRadiativeParticles.slang:179-207) against its restatement in
+    oracle/per_ray_torch (_ReferenceUndoColour) on the per-pixel order recorded by the C oracle.  The scene is given negative
+    SH dc terms on a third of the Gaussians so that the two forms really differ; the test also checks that they do, and that
+    the option changes nothing on a scene without negative colours."""
+    prt = importlib.import_module("oracle.per_ray_torch")
+    K = 8
+    mk, kind, W, H, (eye, tgt), kw = CASES[name]
+    sc = mk()
+    sc["features"] = sc["features"].copy()
+    sc["features"][::3, 0:3] -= 2.5      # colour = 0.282 * dc + 0.5 + ... < 0 on these
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    rng = np.random.default_rng(8)
+    rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
+    model, d12, sph = _oracle_inputs(sc, 3)
+    fwd = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    assert (fwd["feat"][fwd["tiles_count"] > 0] < 0).any()
+    max_order = int(fwd["hits"].max()) + 64
+    ref = oracle.render_kbuffer(view["oracle_cam"], fwd, K=K, max_order=max_order)
+    L = max(int(ref["order_count"].max()), 1)
+    grads = {}
+    for mode in (False, True):
+        params = dict(positions=d12[:, 0:3], density=d12[:, 3:4], rotation=d12[:, 4:8], scale=d12[:, 8:11], features=sph)
+        params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+        rgba, dist = prt.composite_ordered(params, view["tq"], W, H, view["ro"], view["rd"], ref["order_ids"][:, :L], ref["order_count"],
+                                           reference_undo_colour=mode)
+        assert np.abs(rgba.detach().numpy().reshape(H, W, 4) - ref["rgba"]).max() <= 5e-5
+        (rgba * torch.tensor(rgba_grad.reshape(-1, 4), dtype=torch.float64)).sum().backward()
+        dens_g = np.zeros((d12.shape[0], 12))
+        dens_g[:, 0:3] = params["positions"].grad.numpy(); dens_g[:, 3:4] = params["density"].grad.numpy()
+        dens_g[:, 4:8] = params["rotation"].grad.numpy(); dens_g[:, 8:11] = params["scale"].grad.numpy()
+        grads[mode] = _activated_grads(model, dens_g, params["features"].grad.numpy())
+    # the two forms differ on the geometry / density gradients (not on the colour gradient) of this scene ...
+    assert rel_l2(grads[True]["density"], grads[False]["density"]) > 1e-2
+    assert rel_l2(grads[True]["features_albedo"], grads[False]["features_albedo"]) <= 1e-12
+    # ... and the kernel follows whichever is selected
+    for mode in (False, True):
+        model.zero_grad(set_to_none=True)
+        _run_sorted(view, model, K, rgba_grad=rgba_grad, reference_backward=mode)
+        for k, e in grads[mode].items():
+            g = getattr(model, k).grad.cpu().numpy()
+            assert rel_l2(g, e) <= 2e-3, f"{name}/{k} reference_backward={mode}: rel L2 {rel_l2(g, e)}"
 
 
 def test_unusable_rays_do_not_poison_gradients():
