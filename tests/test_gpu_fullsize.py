@@ -166,3 +166,49 @@ def test_full_size_frame_against_the_oracle(frame):
         assert rel_l2(g12[:, sl], dens_g[:, sl]) <= 2e-3, name
     assert rel_l2(g48, sph_g) <= 2e-3
     assert frame["stats"]["num_intersections"] == ref["M"] and frame["raster"].stats()["traversed_bwd"] == ref["traversed_bwd"]
+
+
+def test_two_pass_optimiser_at_full_size_with_finely_interleaved_rows():
+    """The early (side-stream) and the late optimiser pass run CONCURRENTLY at this size and, with the scene's random row order,
+    write rows that share cache lines (48-byte rows, 64/128-byte lines) from different XCDs.  Their union must still be exactly
+    the one-pass result: rows without tiles bit-identical, rows with tiles to the float-atomic noise of the backward, for the
+    parameters, both moments and the activations, over two steps on two views."""
+    sc = scenes.scene_outdoor_like(n=N, seed=2)
+    ro, rd = cams.pinhole_rays(W, H, FX, FX)
+    K = cams.pinhole_intrinsics_dict(W, H, FX, FX)
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(4)).to(DEV)
+    steppers = []
+    for overlap in (False, True):
+        model = native.NativeGaussianModel(sc, device=DEV)            # scene order: rows with / without tiles interleave finely
+        steppers.append(native.NativeTrainStep(model, gut.Tracer({"render": {"enable_kernel_timings": True}}), scene_extent=5.0,
+                                               overlap_optimizer=overlap))
+    ref, ovl = steppers
+    state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48, act=st.act)
+    for k in range(2):
+        for name, t in state(ovl).items():
+            t.copy_(state(ref)[name])
+        c2w = cams.orbit_c2w(4.5, 7.0 + 45.0 * k, 12.0)
+        for st in (ref, ovl):
+            st.step(gut.Batch(rays_ori=torch.as_tensor(ro, device=DEV), rays_dir=torch.as_tensor(rd, device=DEV),
+                              T_to_world=torch.as_tensor(c2w)[None], rgb_gt=gt, intrinsics_OpenCVPinholeCameraModelParameters=K))
+        torch.cuda.synchronize()
+        cnt = ovl.raster.debug_buffer("tiles_count")
+        assert torch.equal(cnt, ref.raster.debug_buffer("tiles_count"))
+        early = cnt == 0
+        assert 1_000_000 < int(early.sum()) < N - 1_000_000
+        for name, t in state(ovl).items():
+            r = state(ref)[name]
+            assert torch.equal(r[early], t[early]), f"step {k}: {name} (rows without tiles)"
+            a, b = r[~early], t[~early]
+            if name in ("m12", "m48", "v12", "v48"):
+                # moments are (sums of) the gradients: equal up to the float-atomic noise of the compositing backward
+                tol = 1e-5 * float(a.abs().max()) + 1e-12
+                assert float((a - b).abs().max()) <= 2 * tol, f"step {k}: {name} (rows with tiles)"
+            else:
+                # Adam's update is ~ lr * sign(g) while the second moment is young: where a gradient component is pure atomic
+                # noise its sign, hence the parameter, may differ by 2 lr; a clobbered row would differ everywhere
+                differs = (a - b).abs() > 1e-6 + 1e-5 * a.abs()
+                assert float(differs.float().mean()) < 2e-3, f"step {k}: {name}: {float(differs.float().mean())} of the elements differ"
+                assert float((a - b).abs().max()) <= 0.12, f"step {k}: {name} (rows with tiles)"
+    kt = ovl.raster.kernel_times()
+    assert kt["optimizer_early"] > 0 and kt["optimizer"] > 0

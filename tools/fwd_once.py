@@ -18,7 +18,7 @@ b = gut.Batch(rays_ori=torch.as_tensor(ro, device=dev), rays_dir=torch.as_tensor
               T_to_world=torch.as_tensor(cams.orbit_c2w(4.5, 7.0, 12.0), device=dev)[None], intrinsics_OpenCVPinholeCameraModelParameters=K)
 if step:
     native = importlib.import_module("3dgrut_amd.native")
-    nm = native.NativeGaussianModel(sc, device=dev)
+    nm = native.NativeGaussianModel(sc, device=dev, spatial_order=True)   # the bench's default storage order (two-pass optimiser on)
     ts = native.NativeTrainStep(nm, tr, scene_extent=5.0)
     b.T_to_world = b.T_to_world.cpu()
     b.rgb_gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(1)).to(dev)

@@ -11,7 +11,7 @@ os.makedirs(dst, exist_ok=True)
 # (regex on the demangled kernel name, bench key).  Templated names: k_render<true>(, k_render_backward<false>(, k_sh_adam<true>(
 KEYS = [(r"\bk_project_on_tiles\b", "project"), (r"\bk_expand_tiles\b", "expand"), (r"\bk_tile_ranges\b", "ranges"),
         (r"\bk_render(<[^>]*>)?\(", "render"), (r"\bk_render_backward\b", "render_bwd"), (r"\bk_project_backward", "project_bwd"),
-        (r"\bk_sh_adam\b", "optimizer"), (r"\bk_adam_rows\b", "optimizer_early"), (r"onesweep|radix_sort|OneSweep", "sort"),
+        (r"\bk_sh_adam\b", "optimizer"), (r"\bk_adam_rows_without_gradient\b", "optimizer_early"), (r"onesweep|radix_sort|OneSweep", "sort"),
         (r"\bk_ssim_|k_photometric", "loss")]
 VALU_ISSUE_NS = 1.16      # one wave64 v_fma_f32 per SIMD every 1.16 ns with >= 2 waves resident (tools/pk_rate.hip, measured)
 SIMDS = 1024
@@ -73,7 +73,9 @@ sq = {"note": "separate rocprofv3 --pmc passes (SQ_A, SQ_B, TCC) over tools/fwd_
               "the chip as rocprofv3 reports them.  duration_ms is the kernel-trace duration in the SAME (profiled) pass.  "
               f"valu_issue_frac = SQ_INSTS_VALU x {VALU_ISSUE_NS} ns / ({SIMDS} SIMDs x duration): share of the chip's measured wave64 VALU "
               "issue rate (tools/pk_rate.hip) the kernel's vector instructions account for.  valu_active_frac = 4 x SQ_ACTIVE_INST_VALU / "
-              "(4 x SQ_BUSY_CYCLES): SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md, cycle constants).  "
+              "({SIMDS} SIMDs x GRBM_GUI_ACTIVE / 8): SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles, GRBM_GUI_ACTIVE is summed "
+              "over the 8 XCDs (MI355X_MICROARCH.md, cycle constants and DVFS section); ~1.0 means the vector pipes never idle.  "
+              "wave_wait_share / wave_issue_stall_share = SQ_WAIT_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES.  "
               "atomic_GBps = TCC_EA0_ATOMIC_sum x 64 B / duration (chip-wide float-atomic rate is about 1300 GB/s).",
       "kernels": {}}
 for p in ("SQ_A", "SQ_B", "TCC"):
@@ -86,8 +88,13 @@ for p in ("SQ_A", "SQ_B", "TCC"):
 for k, e in sq["kernels"].items():
     if "SQ_INSTS_VALU" in e and "duration_ms_SQ_A" in e:
         e["valu_issue_frac"] = e["SQ_INSTS_VALU"] * VALU_ISSUE_NS * 1e-9 / (SIMDS * e["duration_ms_SQ_A"] * 1e-3)
-    if e.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in e:
-        e["valu_active_frac"] = e["SQ_ACTIVE_INST_VALU"] / e["SQ_BUSY_CYCLES"]
+    if e.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in e:
+        e["valu_active_frac"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / (SIMDS * e["GRBM_GUI_ACTIVE"] / 8.0)
+        e["clock_GHz"] = e["GRBM_GUI_ACTIVE"] / 8.0 / (e["duration_ms_SQ_A"] * 1e-3) / 1e9
+    if e.get("SQ_WAVE_CYCLES") and e.get("SQ_WAIT_ANY") is not None and e.get("SQ_WAVES"):
+        # SQ_A and SQ_B are separate passes of the same work: shares of a wave's lifetime
+        e["wave_wait_share"] = e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]
+        e["wave_issue_stall_share"] = e.get("SQ_WAIT_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"]
     if "TCC_EA0_ATOMIC_sum" in e and "duration_ms_TCC" in e:
         e["atomic_GBps"] = e["TCC_EA0_ATOMIC_sum"] * 64 / (e["duration_ms_TCC"] * 1e-3) / 1e9
     if "SQ_WAVE_CYCLES" in e and "SQ_WAIT_ANY" in e:
@@ -116,7 +123,7 @@ L = ["# Profiles (" + rnd + ")\n",
      f"{plain['roofline'].get('box_copy_GBps', float('nan')):.0f} GB/s.\n",
      "Per-kernel counters (per launch):\n",
      "| kernel | duration ms (profiled) | HBM bytes (2xFETCH+WRITE) | uncorrected | VALU wave-instr | valu_issue_frac | valu_active_frac | LDS instr | bank-conflict cycles | atomic GB/s |\n|---|---|---|---|---|---|---|---|---|---|"]
-for k in ("project", "expand", "render", "render_bwd", "optimizer", "optimizer_early"):
+for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimizer", "optimizer_early"):
     e, t = sq["kernels"].get(k, {}), traffic["kernels"].get(k, {})
     if not e and not t:
         continue
