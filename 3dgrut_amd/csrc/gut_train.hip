@@ -379,13 +379,16 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
         if (num_cus <= 0) num_cus = 256;
     }
     const uint32_t nblocks = block_end - block_begin;
-    static int wgs_per_cu = 0;
+    static int wgs_per_cu = 0, wgs_per_cu2 = 0;
     if (wgs_per_cu == 0) {
         const char* e = getenv("GUT_EARLY_WGS_PER_CU");  // tuning experiments only
         wgs_per_cu = e ? atoi(e) : 2;
         if (wgs_per_cu < 1 || wgs_per_cu > 8) wgs_per_cu = 2;
+        const char* e2 = getenv("GUT_EARLY_WGS_PER_CU2");  // second launch (under the backward compositor)
+        wgs_per_cu2 = e2 ? atoi(e2) : wgs_per_cu;
+        if (wgs_per_cu2 < 1 || wgs_per_cu2 > 8) wgs_per_cu2 = wgs_per_cu;
     }
-    const uint32_t cap = (uint32_t)wgs_per_cu * (uint32_t)num_cus;
+    const uint32_t cap = (uint32_t)(block_begin == 0 ? wgs_per_cu : wgs_per_cu2) * (uint32_t)num_cus;
     const uint32_t grid = nblocks < cap ? nblocks : cap;
     hipLaunchKernelGGL(k_adam_rows_without_gradient, dim3(grid), dim3(kBlock), 0, s, a12, a48, n, tiles_count,
                        reinterpret_cast<float4*>(raw12), reinterpret_cast<float4*>(raw_m), reinterpret_cast<float4*>(raw_v),

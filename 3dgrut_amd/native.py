@@ -143,7 +143,10 @@ class NativeTrainStep:
         # low-priority side stream under the compositing kernels (SplatRaster.optimize_rows_without_gradient)
         # Default: on when the model keeps its rows in spatial order (measured on the 6 M-Gaussian bench frame: -9 % step time
         # with Morton-ordered rows, +3 % with randomly ordered ones, where both passes end up touching most 128-byte blocks).
-        self.overlap_optimizer = bool(getattr(model, "spatial_order", False)) if overlap_optimizer is None else bool(overlap_optimizer)
+        # Below ~1 M Gaussians the optimiser is a few percent of the step and the side-stream pass only costs (lego-like 300 k:
+        # 877 -> 851 images/s), so the default also asks for a model of that size.
+        self.overlap_optimizer = (bool(getattr(model, "spatial_order", False)) and model.num_gaussians >= 1_000_000) \
+            if overlap_optimizer is None else bool(overlap_optimizer)
         self.dp_chunks, self.dp_chunk_min_rows = max(1, int(dp_chunks)), int(dp_chunk_min_rows)
         self.lambda_l1, self.lambda_ssim = float(lambda_l1), float(lambda_ssim)
         self._loss_ws = None

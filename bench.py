@@ -84,7 +84,7 @@ def make_views(cams, n_views, W, H, fx, radius, elev, fisheye=False):
     return ro, rd, views
 
 
-def cpu_baseline(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degree, budget_s=30.0):
+def cpu_baseline(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degree, budget_s=30.0, fisheye=False):
     """The CPU restatement of the path (oracle/gut_oracle.c, gcc -O2 -fopenmp) on ONE full frame of the same workload:
     projection + binning + sort + compositing forward, then the compositing / projection backward.  No loss, no optimiser:
     it is the renderer's share of a train step, so the ratio to `value` flatters the CPU.  If the forward alone exceeds the
@@ -92,10 +92,16 @@ def cpu_baseline(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degree, budget_s=3
     oracle = importlib.import_module("oracle.oracle")
     scn = importlib.import_module("3dgrut_amd.scenes")
     tq = pose_mod.sensor_pose_from_c2w(c2w).T_world_sensors[0]
-    K = cams_mod.pinhole_intrinsics_dict(W, H, fx, fx)
-    ocam = dict(model="pinhole", principal_point=K["principal_point"], focal_length=K["focal_length"], radial=K["radial_coeffs"],
-                tangential=K["tangential_coeffs"], thin_prism=K["thin_prism_coeffs"], pose_start=tq)
-    ro, rd = cams_mod.pinhole_rays(W, H, fx, fx)
+    if fisheye:
+        K = cams_mod.fisheye_intrinsics_dict(W, H, fx, fx)
+        ocam = dict(model="fisheye", principal_point=K["principal_point"], focal_length=K["focal_length"],
+                    radial=list(K["radial_coeffs"]), max_angle=K["max_angle"], pose_start=tq)
+        ro, rd = cams_mod.fisheye_rays(W, H, fx, fx)
+    else:
+        K = cams_mod.pinhole_intrinsics_dict(W, H, fx, fx)
+        ocam = dict(model="pinhole", principal_point=K["principal_point"], focal_length=K["focal_length"], radial=K["radial_coeffs"],
+                    tangential=K["tangential_coeffs"], thin_prism=K["thin_prism_coeffs"], pose_start=tq)
+        ro, rd = cams_mod.pinhole_rays(W, H, fx, fx)
     d12 = scn.pack_density(scene)
     threads = int(oracle.lib().oracle_max_threads())
     t0 = time.time()
@@ -427,12 +433,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                if res["fisheye"]:
-                    raise RuntimeError("the CPU baselines are wired for the pinhole workloads")
-                out["cpu_baseline"] = cpu_baseline(res["scene"], res["cams"], res["pose_mod"], W, H, fx, res["c2ws"][0], sh_degree)
-                # north_star's wording: a pure-PyTorch per-ray composite on the host cores, same run (second, smaller sample)
-                out["cpu_baseline_per_ray_torch"] = cpu_baseline_per_ray_torch(res["scene"], res["cams"], res["pose_mod"], W, H, fx,
-                                                                               res["c2ws"][0], sh_degree)
+                out["cpu_baseline"] = cpu_baseline(res["scene"], res["cams"], res["pose_mod"], W, H, fx, res["c2ws"][0], sh_degree,
+                                                   fisheye=res["fisheye"])
+                # north_star's wording: a pure-PyTorch per-ray composite on the host cores, same run (second, smaller sample;
+                # wired for the pinhole workloads)
+                if not res["fisheye"]:
+                    out["cpu_baseline_per_ray_torch"] = cpu_baseline_per_ray_torch(res["scene"], res["cams"], res["pose_mod"], W, H, fx,
+                                                                                   res["c2ws"][0], sh_degree)
             except Exception as e:  # the baseline is reported, never a gate
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
