@@ -289,3 +289,41 @@ def test_spatial_storage_order_is_transparent():
     bt = to_batch(view, DEV); bt.T_to_world = bt.T_to_world.cpu(); bt.rgb_gt = gt
     loss, _ = b.step(bt)
     assert np.isfinite(float(loss))
+
+
+def test_selective_adam_inside_the_fused_optimiser_kernel():
+    """SelectiveAdam semantics (optimizers.cu:47-117: rows with visibility == 0 are skipped entirely, no bias correction)
+    inside k_sh_adam — the one-pass form and the chunked compact form — against the plain per-tensor path
+    (gut_adam_step with the visibility mask, itself checked against the closed form in test_selective_adam_semantics)."""
+    sc = scenes.scene_c1(3000, 23)
+    W, H = 128, 96
+    # camera inside the cloud: a good part of the Gaussians is behind it (visibility 0)
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.1, 0.0, 0.0), (1.0, 0.2, 0.1)), fx=110.0)
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(6)).to(DEV)
+    variants = dict(plain=dict(fused_sh_adam=False), one_pass=dict(fused_sh_adam=True),
+                    chunked=dict(fused_sh_adam=True, fuse_epilogue=False))
+    res = {}
+    for name, kw in variants.items():
+        model = native.NativeGaussianModel(sc, device=DEV)
+        st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, selective=True, **kw)
+        raw0, feat0 = model.raw.clone(), model.features.clone()
+        vis = torch.zeros(model.num_gaussians, dtype=torch.bool, device=DEV)
+        for _ in range(2):
+            b = to_batch(view, DEV); b.T_to_world = b.T_to_world.cpu(); b.rgb_gt = gt
+            _, aux = st.step(b)
+            vis |= aux["mog_visibility"].reshape(-1) > 0      # visible in either step (a few rows change sides as they move)
+        res[name] = dict(raw=model.raw.clone(), feat=model.features.clone(), m48=st.m48.clone(), vis=vis, raw0=raw0, feat0=feat0)
+    vis = res["plain"]["vis"]
+    assert 200 < int(vis.sum()) < 2800
+    for name, r in res.items():
+        assert float((r["vis"] != vis).float().mean()) < 1e-2
+        vis = vis | r["vis"]
+    for name, r in res.items():
+        # invisible rows: parameters and moments untouched, bit for bit
+        assert torch.equal(r["raw"][~vis], r["raw0"][~vis]) and torch.equal(r["feat"][~vis], r["feat0"][~vis]), name
+        assert float(r["m48"][~vis].abs().max()) == 0.0, name
+        assert float((r["raw"][vis] - r["raw0"][vis]).abs().max()) > 0
+    for name in ("one_pass", "chunked"):
+        assert rel_l2(res[name]["raw"].cpu().numpy(), res["plain"]["raw"].cpu().numpy()) <= 1e-5, name
+        assert rel_l2(res[name]["feat"].cpu().numpy(), res["plain"]["feat"].cpu().numpy()) <= 1e-5, name
+        assert rel_l2(res[name]["m48"].cpu().numpy(), res["plain"]["m48"].cpu().numpy()) <= 1e-4, name
