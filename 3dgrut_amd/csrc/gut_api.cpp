@@ -770,7 +770,11 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     if (!h->side_stream) {
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
+        const char* pe = getenv("GUT_SIDE_STREAM_PRIORITY");  // experiments: "default" | "high" | unset = lowest
+        int prio = least;
+        if (pe && pe[0] == 'd') prio = 0;
+        if (pe && pe[0] == 'h') prio = greatest;
+        HIP_TRY(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio));
     }
     if (!h->ev_early_done) HIP_TRY(hipEventCreateWithFlags(&h->ev_early_done, hipEventDisableTiming));
     HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_projected, 0));

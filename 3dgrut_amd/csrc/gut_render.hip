@@ -105,11 +105,12 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     const uint32_t total = range.y - range.x;
     bool alive = ray.valid;
     float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dsum = 0.f;
-    uint32_t nhits = 0, consumed = 0, ordered = 0;  // ordered: entries of the list written to ordered_ids (block-uniform)
+    uint32_t nhits = 0, consumed = 0;
     bool have_lo = false;           // kLazy: the last list entry ordered so far (block-uniform)
     uint32_t lo_d = 0, lo_p = 0, batch_n = 0, batch_used = 0;
 
-    for (uint32_t base = 0; base < total; base += kBlock) {
+    uint32_t base = 0;  // list entries staged so far (kept after the loop: the ordered prefix handed to the backward)
+    for (; base < total; base += kBlock) {
         if (!__syncthreads_or(alive ? 1 : 0)) break;  // whole tile terminated (gutKBufferRenderer.cuh:234-236)
         {
             const uint32_t k = range.x + base + tid;
@@ -129,7 +130,6 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                     ordered_ids[k] = id;
                 }
                 batch_used += take;
-                ordered = base + take;
             } else if (k < range.y) {
                 id = sorted_ids[k];
             }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     __syncthreads();
     if (tid == 0) {
         tile_traversed[tile] = s_deepest;
-        if (kLazy) tile_ordered[tile] = ordered;  // the backward reads ordered_ids[range.x .. range.x + ordered) only
+        if (kLazy) tile_ordered[tile] = min(base, total);  // the backward reads ordered_ids[range.x .. range.x + that) only
     }
 }
 

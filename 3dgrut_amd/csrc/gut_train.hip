@@ -151,6 +151,20 @@ __device__ __forceinline__ void adam4(const AdamParams& ap, uint32_t c0, const f
 #undef GUT_ADAM_LANE
 }
 
+// adam4 with a zero gradient and the four learning rates handed over (bit-identical to adam4(ap, c0, 0, ...): the gradient
+// terms are exact zeros there too)
+__device__ __forceinline__ void adam4_zero_grad(const AdamParams& ap, const float4& lr, float4& p, float4& m, float4& v) {
+#define GUT_ADAM_LANE(X)                                   \
+    m.X = ap.beta1 * m.X + (1.0f - ap.beta1) * 0.0f;       \
+    v.X = ap.beta2 * v.X + (1.0f - ap.beta2) * 0.0f * 0.0f; \
+    p.X -= lr.X * m.X * __builtin_amdgcn_rcpf(sqrt_approx_pos(v.X) * ap.bias2_sqrt + ap.eps);
+    GUT_ADAM_LANE(x)
+    GUT_ADAM_LANE(y)
+    GUT_ADAM_LANE(z)
+    GUT_ADAM_LANE(w)
+#undef GUT_ADAM_LANE
+}
+
 // kScratch = true (one view, no exchange): the per-Gaussian epilogue of the backward (K8c) is folded in — grad12 then points
 // at the renderer's 64-byte gradient rows [pos3, density, quat4, scale3, rgb3, pad2] w.r.t. the ACTIVATED parameters, which
 // are chained to the raw parameters here (the activations are recomputed from the raw row the optimiser loads anyway, with
@@ -176,10 +190,10 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
     if (i < sp.n) {
         active = !(visibility && !(visibility[i] != 0.0f));
         if (kScratch && sp.rows_with_tiles_only && tiles_count[i] == 0) active = false;
-        float4 a = p12[3 * (size_t)i + 0];
-        const float px = a.x, py = a.y, pz = a.z;  // pre-update position: the direction the forward used
         if (active) {
             // --- raw [N,12] row ---
+            float4 a = p12[3 * (size_t)i + 0];
+            const float px = a.x, py = a.y, pz = a.z;  // pre-update position: the direction the forward used
             float4 b = p12[3 * (size_t)i + 1], c = p12[3 * (size_t)i + 2];
             float4 g0, g1, g2;
             float own_r = 0.f, own_g = 0.f, own_b = 0.f;  // kScratch: this view's masked dL/dRGB
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
             }
         }
     }
+    if (__ballot(active) == 0ull) return;  // wave-uniform: none of the wave's 64 rows is updated by this launch
     // stage gradients + row-active flag (column 48) in the wave-private LDS tile
 #pragma unroll
     for (int k = 0; k < 48; ++k) wl[lane * kRow + k] = G[k];
@@ -279,13 +294,16 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
 // iteration; k_sh_adam<true> then only walks the rows that have tiles.  Same adam4 arithmetic, same activation: the
 // parameters after the step are bit-identical to the one-pass kernel's.  One wave per 64 Gaussians; the [N,48] sweep is the
 // same coalesced 16-byte pattern with a per-row predicate taken from the wave's ballot.
-// Launch shape: PERSISTENT with a fixed, small footprint — gridDim.x = 2 workgroups per CU (8 waves per CU, 2 per SIMD,
-// <= 64 VGPRs each, no LDS), every workgroup striding over the 256-row blocks.  It is queued in front of the compositing
-// kernel, so its workgroups take their two wave slots per SIMD first and keep them until the pass is done; the compositing
-// and loss kernels get everything else and are never queued behind a wall of streaming workgroups (a one-block-per-256-rows
-// grid on a low-priority stream starved the image-sized loss kernels: measured 0.14 -> 0.8 ms).  8 waves per CU with 12
-// 16-byte loads in flight each are enough to keep a CU's share of the HBM stream busy.
-__global__ __launch_bounds__(kBlock, 8) void k_adam_rows_without_gradient(AdamParams a12, AdamParams a48, uint32_t n,
+// Launch shape: PERSISTENT with a fixed, small footprint — gridDim.x = 1 workgroup per CU (one wave per SIMD, 78 VGPRs, 192 B
+// of LDS), every workgroup striding over the 256-row blocks.  It is queued in front of the compositing kernel, so its
+// workgroups take their wave slot per SIMD first and keep it until the pass is done; the compositing and loss kernels get
+// everything else and are never queued behind a wall of streaming workgroups (a one-block-per-256-rows grid on a low-priority
+// stream starved the image-sized loss kernels: measured 0.14 -> 0.8 ms).  One wave per SIMD with twelve 16-byte loads in
+// flight (the [N,48] sweep is unrolled four times) keeps a CU's share of the HBM stream busy; two waves per SIMD at half the
+// registers moved the same bytes but spilled to scratch at the 64-VGPR bound.  NO SCRATCH is a requirement, not a nicety:
+// this kernel runs on a second hardware queue beside K6, which has a 32-byte spill area of its own, and with both queues
+// claiming scratch the forward compositor was occasionally (1 process in ~15) 3x slower for the whole process.
+__global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamParams a12, AdamParams a48, uint32_t n,
                                                                           const uint32_t* __restrict__ tiles_count,
                                                                           float4* __restrict__ p12, float4* __restrict__ m12,
                                                                           float4* __restrict__ v12, float4* __restrict__ p48,
@@ -294,6 +312,12 @@ __global__ __launch_bounds__(kBlock, 8) void k_adam_rows_without_gradient(AdamPa
                                                                           uint32_t block_end) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the [N,48] sweep picks its four learning rates by a per-lane column: keep them in LDS (a register-indexed kernel
+    // argument array would live in scratch, and this kernel must not use any: it runs beside other kernels on another queue)
+    __shared__ float4 s_lr48[12];
+    if (threadIdx.x < 12) s_lr48[threadIdx.x] = make_float4(a48.lr[4 * threadIdx.x], a48.lr[4 * threadIdx.x + 1], a48.lr[4 * threadIdx.x + 2],
+                                                           a48.lr[4 * threadIdx.x + 3]);
+    __syncthreads();
     for (uint32_t blk = block_begin + blockIdx.x; blk < block_end; blk += gridDim.x) {
         const uint32_t i = blk * kBlock + threadIdx.x;
         const uint32_t wave_first = blk * kBlock + wave * 64u;
@@ -302,28 +326,32 @@ __global__ __launch_bounds__(kBlock, 8) void k_adam_rows_without_gradient(AdamPa
         const unsigned long long mask = __ballot(mine);
         if (mask == 0ull) continue;  // wave-uniform
         if (mine) {
-            float4 a = p12[3 * (size_t)i + 0], b = p12[3 * (size_t)i + 1], c = p12[3 * (size_t)i + 2];
-            float4 ma = m12[3 * (size_t)i + 0], mb = m12[3 * (size_t)i + 1], mc = m12[3 * (size_t)i + 2];
-            float4 va = v12[3 * (size_t)i + 0], vb = v12[3 * (size_t)i + 1], vc = v12[3 * (size_t)i + 2];
-            adam4(a12, 0, zero, a, ma, va);
-            adam4(a12, 4, zero, b, mb, vb);
-            adam4(a12, 8, zero, c, mc, vc);
-            p12[3 * (size_t)i + 0] = a; p12[3 * (size_t)i + 1] = b; p12[3 * (size_t)i + 2] = c;
-            m12[3 * (size_t)i + 0] = ma; m12[3 * (size_t)i + 1] = mb; m12[3 * (size_t)i + 2] = mc;
-            v12[3 * (size_t)i + 0] = va; v12[3 * (size_t)i + 1] = vb; v12[3 * (size_t)i + 2] = vc;
+            // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
+            // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
+            float4 a = p12[3 * (size_t)i + 0], m = m12[3 * (size_t)i + 0], v = v12[3 * (size_t)i + 0];
+            adam4(a12, 0, zero, a, m, v);
+            p12[3 * (size_t)i + 0] = a; m12[3 * (size_t)i + 0] = m; v12[3 * (size_t)i + 0] = v;
+            float4 b = p12[3 * (size_t)i + 1];
+            m = m12[3 * (size_t)i + 1]; v = v12[3 * (size_t)i + 1];
+            adam4(a12, 4, zero, b, m, v);
+            p12[3 * (size_t)i + 1] = b; m12[3 * (size_t)i + 1] = m; v12[3 * (size_t)i + 1] = v;
+            float4 c = p12[3 * (size_t)i + 2];
+            m = m12[3 * (size_t)i + 2]; v = v12[3 * (size_t)i + 2];
+            adam4(a12, 8, zero, c, m, v);
+            p12[3 * (size_t)i + 2] = c; m12[3 * (size_t)i + 2] = m; v12[3 * (size_t)i + 2] = v;
             if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
         }
         float4* bp = p48 + (size_t)wave_first * 12;
         float4* bm = m48 + (size_t)wave_first * 12;
         float4* bv = v48 + (size_t)wave_first * 12;
-#pragma unroll 2
+#pragma unroll 4
         for (int it = 0; it < 12; ++it) {
             const uint32_t q = (uint32_t)it * 64u + lane;
             if (q >= rows_here * 12u) continue;
             const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
             if (!((mask >> row) & 1ull)) continue;
             float4 pp = bp[q], mm = bm[q], vv = bv[q];
-            adam4(a48, col, zero, pp, mm, vv);
+            adam4_zero_grad(a48, s_lr48[col >> 2], pp, mm, vv);
             bp[q] = pp; bm[q] = mm; bv[q] = vv;
         }
     }
@@ -382,8 +410,8 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
     static int wgs_per_cu = 0, wgs_per_cu2 = 0;
     if (wgs_per_cu == 0) {
         const char* e = getenv("GUT_EARLY_WGS_PER_CU");  // tuning experiments only
-        wgs_per_cu = e ? atoi(e) : 2;
-        if (wgs_per_cu < 1 || wgs_per_cu > 8) wgs_per_cu = 2;
+        wgs_per_cu = e ? atoi(e) : 1;
+        if (wgs_per_cu < 1 || wgs_per_cu > 8) wgs_per_cu = 1;
         const char* e2 = getenv("GUT_EARLY_WGS_PER_CU2");  // second launch (under the backward compositor)
         wgs_per_cu2 = e2 ? atoi(e2) : wgs_per_cu;
         if (wgs_per_cu2 < 1 || wgs_per_cu2 > 8) wgs_per_cu2 = wgs_per_cu;

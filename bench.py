@@ -69,8 +69,7 @@ def algorithmic_bytes(st, kernel, end_bit):
         "optimizer": 1492 * N + 76 * V,
         # split form (default at one view): the rows without tiles (N - V) are updated by k_adam_rows_without_gradient on a side
         # stream under the compositing kernels, k_sh_adam then walks the V rows with tiles; both read every tile count (4 N)
-        # and the late pass the position row of every Gaussian (16 N, one float4)
-        "optimizer_late": 4 * N + 16 * (N - V) + (1488 + 76) * V,
+        "optimizer_late": 4 * N + (1488 + 76) * V,
         "optimizer_early": 4 * N + 1488 * (N - V),
     }[kernel]
 
