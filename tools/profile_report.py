@@ -24,12 +24,24 @@ def key_of(name):
     return None
 
 
+def _second_half(rows_by_name):
+    """fwd_once runs two train steps: keep each kernel's dispatches of the LAST step (the first dispatch of a kernel with a
+    spill area — K6 — can include the runtime's one-off scratch set-up, 0.54 -> 1.45 ms)."""
+    out = []
+    for rows in rows_by_name.values():
+        out.extend(rows[len(rows) // 2:])
+    return out
+
+
 def counters(pass_name):
     files = glob.glob(os.path.join(src, "pmc_" + pass_name, "**", "*counter_collection.csv"), recursive=True)
-    acc = {}
     if not files:
-        return acc
+        return {}
+    by = {}
     for r in csv.DictReader(open(files[0])):
+        by.setdefault((r["Kernel_Name"], r["Counter_Name"]), []).append(r)
+    acc = {}
+    for r in _second_half(by):
         k = key_of(r["Kernel_Name"])
         if k:
             acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -40,7 +52,10 @@ def kernel_durations(pass_name):
     files = glob.glob(os.path.join(src, "pmc_" + pass_name, "**", "*kernel_trace.csv"), recursive=True)
     acc = {}
     if files:
+        by = {}
         for r in csv.DictReader(open(files[0])):
+            by.setdefault(r["Kernel_Name"], []).append(r)
+        for r in _second_half(by):
             k = key_of(r["Kernel_Name"])
             if k:
                 acc.setdefault(k, []).append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
@@ -70,7 +85,7 @@ for k, d in traffic["kernels"].items():
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 sq = {"note": "separate rocprofv3 --pmc passes (SQ_A, SQ_B, TCC) over tools/fwd_once.py 6000000 2 step, mean per launch, values summed over "
-              "the chip as rocprofv3 reports them.  duration_ms is the kernel-trace duration in the SAME (profiled) pass.  "
+              "the chip as rocprofv3 reports them.  duration_ms is the kernel-trace duration in the SAME (profiled) pass; every figure is the mean over the dispatches of the second of the two steps.  "
               f"valu_issue_frac = SQ_INSTS_VALU x {VALU_ISSUE_NS} ns / ({SIMDS} SIMDs x duration): share of the chip's measured wave64 VALU "
               "issue rate (tools/pk_rate.hip) the kernel's vector instructions account for.  valu_active_frac = 4 x SQ_ACTIVE_INST_VALU / "
               "({SIMDS} SIMDs x GRBM_GUI_ACTIVE / 8): SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles, GRBM_GUI_ACTIVE is summed "
