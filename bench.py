@@ -397,6 +397,13 @@ def main():
                     "traffic_source": (prof.get("_source") + " (separate rocprofv3 --pmc passes of the same workload, replayed here)") if traffic else None,
                     "algorithmic_bytes": abytes, "mean_launch_ms": ktimes[dom], "launches_averaged": res["kcount"],
                     "box_copy_GBps": copy_gbs}
+        if split:
+            # context for the split optimiser: what the whole Adam step must move vs what of it is left on the critical path
+            roofline["optimizer_split"] = {
+                "whole_step_algorithmic_bytes": algorithmic_bytes(stats, "optimizer", stats["sort_end_bit"]),
+                "critical_path_kernel_bytes": algorithmic_bytes(stats, "optimizer_late", stats["sort_end_bit"]),
+                "side_stream_kernel_bytes": algorithmic_bytes(stats, "optimizer_early", stats["sort_end_bit"]),
+                "critical_path_ms": ktimes["optimizer"], "side_stream_span_ms": ktimes["optimizer_early"]}
         per_kernel = {}
         for k in ktimes:
             e = {"ms": ktimes[k],
@@ -410,6 +417,9 @@ def main():
                 e["counters_source"] = prof.get("_source")
             if "hbm_bytes" in c:
                 e["traffic"] = c["hbm_bytes"]
+            if k == "optimizer_early" and ktimes[k] > 0:
+                e["note"] = ("side stream, two launches (25 % of the row blocks under the forward compositor, 75 % under the backward "
+                             "compositor): ms is the span from the start of the first to the end of the second, idle gap included")
             per_kernel[k] = e
         sh_degree = 3
         out = {
