@@ -768,11 +768,14 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
     if (!h->side_stream) {
+        // default priority (GUT_SIDE_STREAM_PRIORITY=low|high for experiments): the kernel's fixed footprint is what keeps it
+        // out of the way, not the queue priority — and with a lowest-priority queue the forward compositor was, in about one
+        // process out of ten, 2-3x slower for the whole process (hardware queue arbitration; cause inferred)
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const char* pe = getenv("GUT_SIDE_STREAM_PRIORITY");  // experiments: "default" | "high" | unset = lowest
-        int prio = least;
-        if (pe && pe[0] == 'd') prio = 0;
+        const char* pe = getenv("GUT_SIDE_STREAM_PRIORITY");
+        int prio = 0;
+        if (pe && pe[0] == 'l') prio = least;
         if (pe && pe[0] == 'h') prio = greatest;
         HIP_TRY(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio));
     }

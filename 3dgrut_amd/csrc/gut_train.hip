@@ -300,9 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
 // everything else and are never queued behind a wall of streaming workgroups (a one-block-per-256-rows grid on a low-priority
 // stream starved the image-sized loss kernels: measured 0.14 -> 0.8 ms).  One wave per SIMD with twelve 16-byte loads in
 // flight (the [N,48] sweep is unrolled four times) keeps a CU's share of the HBM stream busy; two waves per SIMD at half the
-// registers moved the same bytes but spilled to scratch at the 64-VGPR bound.  NO SCRATCH is a requirement, not a nicety:
-// this kernel runs on a second hardware queue beside K6, which has a 32-byte spill area of its own, and with both queues
-// claiming scratch the forward compositor was occasionally (1 process in ~15) 3x slower for the whole process.
+// registers moved the same bytes but spilled to scratch at the 64-VGPR bound (this form has no scratch).
 __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamParams a12, AdamParams a48, uint32_t n,
                                                                           const uint32_t* __restrict__ tiles_count,
                                                                           float4* __restrict__ p12, float4* __restrict__ m12,

@@ -107,6 +107,8 @@ class NativeGaussianModel:
 
 
 class NativeTrainStep:
+    OVERLAP_MIN_GAUSSIANS = 1_000_000   # size from which the two-pass optimiser is on by default (see __init__)
+
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
                  betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2,
                  dp_chunks=4, dp_chunk_min_rows=1 << 20, fuse_epilogue=True, schedule=None,
@@ -145,8 +147,13 @@ class NativeTrainStep:
         # with Morton-ordered rows, +3 % with randomly ordered ones, where both passes end up touching most 128-byte blocks).
         # Below ~1 M Gaussians the optimiser is a few percent of the step and the side-stream pass only costs (lego-like 300 k:
         # 877 -> 851 images/s), so the default also asks for a model of that size.
-        self.overlap_optimizer = (bool(getattr(model, "spatial_order", False)) and model.num_gaussians >= 1_000_000) \
+        self.overlap_optimizer = (bool(getattr(model, "spatial_order", False)) and model.num_gaussians >= self.OVERLAP_MIN_GAUSSIANS) \
             if overlap_optimizer is None else bool(overlap_optimizer)
+        # When the overlap is on by DEFAULT (not forced by the caller) it is checked against the one-pass form on this machine
+        # and workload: steps 2..5 alternate the two forms under event timers and the faster one is kept (the two forms leave
+        # bit-identical parameters, so the choice is invisible in the results).  Rows in an unfavourable order, a small visible
+        # fraction or a box whose queues arbitrate badly can each make the one-pass form the faster one.
+        self._overlap_probe = dict(on=[], off=[], done=False) if (overlap_optimizer is None and self.overlap_optimizer) else None
         self.dp_chunks, self.dp_chunk_min_rows = max(1, int(dp_chunks)), int(dp_chunk_min_rows)
         self.lambda_l1, self.lambda_ssim = float(lambda_l1), float(lambda_ssim)
         self._loss_ws = None
@@ -280,10 +287,24 @@ class NativeTrainStep:
         m = self.model
         evs = [] if self.phase_timing else None
         self._mark(evs)
-        rgba, dist_, hits, vis = self.forward(batch)
         one_pass = self.fused and self.world_size <= 1 and not self.force_exchange and self.post_backward_hook is None \
             and self.fuse_epilogue
-        early = one_pass and self.overlap_optimizer and not self.selective
+        use_overlap, probe_evs = self.overlap_optimizer, None
+        probe = self._overlap_probe
+        if probe is not None and one_pass and not self.selective:
+            if 2 <= self.step_id <= 5:      # probing steps: on, off, on, off
+                use_overlap = (self.step_id % 2) == 0
+                probe_evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                probe_evs[0].record()
+                probe["on" if use_overlap else "off"].append(probe_evs)
+            elif self.step_id > 5 and not probe["done"] and all(e[1].query() for e in probe["on"] + probe["off"]):
+                t_on = sum(a.elapsed_time(b) for a, b in probe["on"]) / max(1, len(probe["on"]))
+                t_off = sum(a.elapsed_time(b) for a, b in probe["off"]) / max(1, len(probe["off"]))
+                probe.update(done=True, ms_on=t_on, ms_off=t_off)
+                self.overlap_optimizer = use_overlap = bool(probe["on"]) and bool(probe["off"]) and t_on <= t_off
+        early = one_pass and use_overlap and not self.selective
+        self._probe_evs = probe_evs
+        rgba, dist_, hits, vis = self.forward(batch)
         if early:
             self.raster.optimize_rows_without_gradient(m.raw, self.m12, self.v12, m.features, self.m48, self.v48, self.lr12,
                                                        self.lr48, self.betas, self.eps, self.step_id + 1, self.act)
@@ -393,6 +414,9 @@ class NativeTrainStep:
         return loss.detach(), dict(pred_rgb=pred_rgb.detach(), mog_visibility=vis, hits_count=hits)
 
     def _end_of_step(self, evs):
+        if getattr(self, "_probe_evs", None) is not None:
+            self._probe_evs[1].record()
+            self._probe_evs = None
         if evs is not None:
             self._phase_events.append(evs)
         if self.schedule is not None:   # scheduler_step(g) + SH-degree increase, after the optimiser (trainer.py:756-765)

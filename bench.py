@@ -434,7 +434,9 @@ def main():
                                     (" selective(visibility)" if args.selective_adam else "") + ", all 59 params/Gaussian",
                        "trainer": args.trainer,
                        "storage_order": ("morton" if (args.trainer == "native" and not args.scene_order) else "as generated"),
-                       "optimizer_overlap": bool(getattr(stepper, "overlap_optimizer", False))},
+                       "optimizer_overlap": bool(getattr(stepper, "overlap_optimizer", False)),
+                       "optimizer_overlap_probe_ms": ({k: round(v, 3) for k, v in stepper._overlap_probe.items() if k in ("ms_on", "ms_off")}
+                                                      if getattr(stepper, "_overlap_probe", None) else None)},
             "render_ms_per_frame": res["render_ms"],
             "forward_render_ms_in_train": res["fb"].get("forward_render"), "backward_render_ms_in_train": res["fb"].get("backward_render"),
             "phase_ms": res["phases"], "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,

@@ -327,3 +327,27 @@ def test_selective_adam_inside_the_fused_optimiser_kernel():
         assert rel_l2(res[name]["raw"].cpu().numpy(), res["plain"]["raw"].cpu().numpy()) <= 1e-5, name
         assert rel_l2(res[name]["feat"].cpu().numpy(), res["plain"]["feat"].cpu().numpy()) <= 1e-5, name
         assert rel_l2(res[name]["m48"].cpu().numpy(), res["plain"]["m48"].cpu().numpy()) <= 1e-4, name
+
+
+def test_overlap_probe_keeps_the_faster_optimiser_form(monkeypatch):
+    """With the overlap on by default NativeTrainStep times steps 2..5 alternately with and without it and keeps the faster
+    form; forced settings are never probed.  (Made applicable to a small scene by lowering the size gate.)"""
+    sc = scenes.scene_c1(4000, 9)
+    W, H = 96, 64
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, 0.0, -3.5), (0, 0, 0)), fx=90.0)
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(2)).to(DEV)
+    model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+    forced = native.NativeTrainStep(model, gut.Tracer({"render": {}}), overlap_optimizer=True)
+    assert forced._overlap_probe is None
+    model2 = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+    monkeypatch.setattr(native.NativeTrainStep, "OVERLAP_MIN_GAUSSIANS", 1000)
+    st = native.NativeTrainStep(model2, gut.Tracer({"render": {}}))
+    assert st.overlap_optimizer and st._overlap_probe is not None
+    for _ in range(10):
+        b = to_batch(view, DEV); b.T_to_world = b.T_to_world.cpu(); b.rgb_gt = gt
+        loss, _ = st.step(b)
+        torch.cuda.synchronize()
+    p = st._overlap_probe
+    assert p["done"] and len(p["on"]) == 2 and len(p["off"]) == 2 and p["ms_on"] > 0 and p["ms_off"] > 0
+    assert st.overlap_optimizer == (p["ms_on"] <= p["ms_off"])
+    assert np.isfinite(float(loss))
