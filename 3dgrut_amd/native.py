@@ -150,7 +150,7 @@ class NativeTrainStep:
         self.overlap_optimizer = (bool(getattr(model, "spatial_order", False)) and model.num_gaussians >= self.OVERLAP_MIN_GAUSSIANS) \
             if overlap_optimizer is None else bool(overlap_optimizer)
         # When the overlap is on by DEFAULT (not forced by the caller) it is checked against the one-pass form on this machine
-        # and workload: steps 2..5 alternate the two forms under event timers and the faster one is kept (the two forms leave
+        # and workload: steps 1..4 alternate the two forms under event timers and the faster one is kept (the two forms leave
         # bit-identical parameters, so the choice is invisible in the results).  Rows in an unfavourable order, a small visible
         # fraction or a box whose queues arbitrate badly can each make the one-pass form the faster one.
         self._overlap_probe = dict(on=[], off=[], done=False) if (overlap_optimizer is None and self.overlap_optimizer) else None
@@ -292,12 +292,12 @@ class NativeTrainStep:
         use_overlap, probe_evs = self.overlap_optimizer, None
         probe = self._overlap_probe
         if probe is not None and one_pass and not self.selective:
-            if 2 <= self.step_id <= 5:      # probing steps: on, off, on, off
+            if 1 <= self.step_id <= 4:      # probing steps: off, on, off, on (inside a 5-step warm-up)
                 use_overlap = (self.step_id % 2) == 0
                 probe_evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 probe_evs[0].record()
                 probe["on" if use_overlap else "off"].append(probe_evs)
-            elif self.step_id > 5 and not probe["done"] and all(e[1].query() for e in probe["on"] + probe["off"]):
+            elif self.step_id > 4 and not probe["done"] and all(e[1].query() for e in probe["on"] + probe["off"]):
                 t_on = sum(a.elapsed_time(b) for a, b in probe["on"]) / max(1, len(probe["on"]))
                 t_off = sum(a.elapsed_time(b) for a, b in probe["off"]) / max(1, len(probe["off"]))
                 probe.update(done=True, ms_on=t_on, ms_off=t_off)

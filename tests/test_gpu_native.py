@@ -330,7 +330,7 @@ def test_selective_adam_inside_the_fused_optimiser_kernel():
 
 
 def test_overlap_probe_keeps_the_faster_optimiser_form(monkeypatch):
-    """With the overlap on by default NativeTrainStep times steps 2..5 alternately with and without it and keeps the faster
+    """With the overlap on by default NativeTrainStep times steps 1..4 alternately with and without it and keeps the faster
     form; forced settings are never probed.  (Made applicable to a small scene by lowering the size gate.)"""
     sc = scenes.scene_c1(4000, 9)
     W, H = 96, 64
