@@ -285,7 +285,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -340,14 +340,19 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # nothing in this process has initialised the GPU yet (device_count() does not, on this image)
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get("GUT_BENCH_SHARE_GPU") != "1":
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} started with WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GUT_BENCH_SHARE_GPU=1 + GUT_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks
+    # (ranks share the cards, the exchange is host-staged) — exercises launcher, rendezvous and the data-parallel step; the
+    # number it prints is NOT a bench line
+    share = os.environ.get("GUT_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON line on
     # stdout, so everything before that line is routed to stderr at the file-descriptor level
     sys.stdout.flush()
@@ -361,7 +366,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("GUT_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     env = dict(rank=rank, world=world, dev=dev, dist=dist)
     res = run_workload(args, env, args.workload, args.steps, args.warmup, args.render_frames)
@@ -426,7 +435,8 @@ def main():
             "metric": "train-step images/sec + render ms/frame, MipNeRF360 bicycle @1/2/4/8 GPU",
             "value": res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, host-staged exchange - not a bench line)"
+                                                      if os.environ.get("GUT_BENCH_SHARE_GPU") == "1" else ""),
             "config": {"workload": args.workload, "num_gaussians": int(stats["num_particles"]), "resolution": [W, H],
                        "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}" + ("" if world == 1 else (" dense all-reduce [N,60]" if (args.dense_exchange or args.trainer != "native") else " all-reduce [N,12] + all-gather [N,3]")),
                        "loss": "0.8*L1+0.2*(1-SSIM) (HIP fused SSIM)",
