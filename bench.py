@@ -65,11 +65,12 @@ def algorithmic_bytes(st, kernel, end_bit):
         "render_bwd": 8 * T + 64 * Eb + 64 * P + 112 * V,
         "project_bwd": (40 + 384) * V + 252 * N,
         # one-pass optimiser (k_sh_adam<scratch>): raw p/m/v in+out 288, next activation 48, SH p/m/v in+out 1152, count 4 per
-        # Gaussian; 64-byte gradient row + 12-byte RGB per Gaussian with tiles
-        "optimizer": 1492 * N + 76 * V,
+        # Gaussian; 64-byte gradient row read, 12-byte RGB, and the 64-byte row zeroed again (replaces the per-step clear of the
+        # whole gradient buffer) per Gaussian with tiles
+        "optimizer": 1492 * N + (76 + 64) * V,
         # split form (default at one view): the rows without tiles (N - V) are updated by k_adam_rows_without_gradient on a side
         # stream under the compositing kernels, k_sh_adam then walks the V rows with tiles; both read every tile count (4 N)
-        "optimizer_late": 4 * N + (1488 + 76) * V,
+        "optimizer_late": 4 * N + (1488 + 76 + 64) * V,
         "optimizer_early": 4 * N + 1488 * (N - V),
     }[kernel]
 

@@ -1138,3 +1138,56 @@ void oracle_project_bwd(const OracleCamera* cam, uint32_t N, int sh_degree,
 float oracle_det_logf(float x) { return det_logf(x); }
 float oracle_det_atan2f(float y, float x) { return det_atan2f_pos(y, x); }
 float oracle_tile_min_power(float tx, float ty, const float* conic4, const float* mean2) { return tile_min_power(tx, ty, conic4, mean2); }
+
+/* Layout study (tools only, not used by any test): for the traversal oracle_render performs, count the (wave, list entry) pairs
+ * in which at least one of the wave's 64 pixels is hit, for two assignments of a 16x16 tile's pixels to four waves:
+ * out[0] = 16x4 strips (wave = py_in_tile / 4), out[1] = 8x8 blocks (wave = (py_in_tile / 8) * 2 + px_in_tile / 8),
+ * out[2] = hit (pixel, entry) pairs, out[3] = (tile, entry) pairs walked while any pixel of the tile was alive. */
+void oracle_count_wave_pairs(const OracleParams* prm, const OracleCamera* cam, int W, int H, const float* density12,
+                             const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
+                             uint64_t* out) {
+    const PoseSet ps = make_pose_set(cam);
+    const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
+    uint64_t c_strip = 0, c_block = 0, c_hits = 0, c_walk = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c_strip, c_block, c_hits, c_walk)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+        Ray rays[256]; float T[256]; int alive[256];
+        for (int p = 0; p < 256; ++p) {
+            const int px = tx * GUT_TILE + (p & 15), py = ty * GUT_TILE + (p >> 4);
+            alive[p] = 0; T[p] = 1.0f;
+            if (px < W && py < H) {
+                const size_t pix = (size_t)py * W + px;
+                rays[p] = make_ray(&ps, ray_ori + 3 * pix, ray_dir + 3 * pix);
+                alive[p] = rays[p].alive;
+            }
+        }
+        for (uint32_t k = beg; k < end; ++k) {
+            int any = 0;
+            for (int p = 0; p < 256; ++p) any |= alive[p];
+            if (!any) break;
+            const uint32_t id = sorted_ids[k];
+            if (id == INVALID_IDX) break;
+            c_walk++;
+            const float* g = density12 + (size_t)id * 12;
+            float rows[3][3];
+            quat_to_rows(g + 4, rows);
+            int strip[4] = {0, 0, 0, 0}, block[4] = {0, 0, 0, 0};
+            for (int p = 0; p < 256; ++p) {
+                if (!alive[p]) continue;
+                Hit h;
+                eval_hit(prm, g, rows, &rays[p], &h);
+                if ((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold)) {
+                    c_hits++;
+                    strip[(p >> 4) >> 2] = 1;
+                    block[((p >> 4) >> 3) * 2 + ((p & 15) >> 3)] = 1;
+                    T[p] *= (1.0f - h.alpha);
+                    if (T[p] < prm->min_transmittance) alive[p] = 0;
+                }
+            }
+            for (int w = 0; w < 4; ++w) { c_strip += strip[w]; c_block += block[w]; }
+        }
+    }
+    out[0] = c_strip; out[1] = c_block; out[2] = c_hits; out[3] = c_walk;
+}
