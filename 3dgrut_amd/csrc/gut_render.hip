@@ -4,8 +4,8 @@
 //   K7 render_backward (reference: gutKBufferRenderer.cuh:294-386, models/gaussianParticles.cuh:480-738,
 //                       shRadiativeGaussianParticles.cuh:409-482)
 //
-// Layout: one 256-thread workgroup (4 wave64) per 16x16 tile, one lane per pixel; each wave owns 4
-// image rows.  The tile's depth-sorted list is consumed in chunks of 256 entries staged in LDS by the
+// Layout: one 256-thread workgroup (4 wave64) per 16x16 tile, one lane per pixel; each wave owns an
+// 8x8 block.  The tile's depth-sorted list is consumed in chunks of 256 entries staged in LDS by the
 // whole workgroup (one entry per lane, coalesced id read + 48-byte parameter gather), converted once
 // to the canonical-space form the inner loop needs (M = diag(1/s) * rotationT, so the per-pixel work
 // is two 3x3 mat-vecs, a cross product and one v_exp_f32).  LDS reads in the inner loop are
@@ -19,7 +19,7 @@
 // which no lane hit the entry skip the reduction altogether (wave-uniform branch on __ballot).
 //
 // Three further pieces live in gut_render_common.h: the per-wave strip culling (double-wedge test of each staged entry's
-// cut-off ellipsoid; every wave walks its own compacted entry list), the lazy per-tile depth order (the global sort only
+// cut-off ellipsoid against the elevation and azimuth wedges of each wave's 8x8 block; every wave walks its own compacted entry list), the lazy per-tile depth order (the global sort only
 // groups by tile; K6 orders 512 entries at a time as far as the tile is walked and hands the ordered ids to K7), and the
 // staging form of an entry.  The backward launches its tiles deepest-first (k_tile_order).
 //
@@ -76,15 +76,15 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                                                      uint32_t* __restrict__ tile_ordered) {
     __shared__ FwdEntry stage[kBlock];
     __shared__ uint32_t s_deepest, s_first_invalid;
-    __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (16x4 strips) can hit it at all
+    __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (8x8 blocks) can hit it at all
     __shared__ uint16_t s_list[kBlock / 64][kBlock];  // per wave: the staged entries it has to evaluate (index), in list order
     __shared__ StripPlanes s_planes;
     __shared__ LazyOrder s_lazy;
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + (int)(tid & 15);
-    const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + (int)(tid >> 4);
+    const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + tile_px(tid);   // wave = 8x8 block (gut_render_common.h)
+    const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + tile_py(tid);
     const bool inside = (px < v.width) && (py < v.height);
     const size_t pix = (size_t)py * (size_t)v.width + (size_t)px;
     // zero intersections: the reference returns before rendering and the outputs keep their initial values
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                 }
             }
         };
-        // The wave first compacts the chunk to the entries whose cut-off ellipsoid can reach its 16x4 strip (ballot prefix,
+        // The wave first compacts the chunk to the entries whose cut-off ellipsoid can reach its 8x8 block (ballot prefix,
         // indices into a wave-private LDS list), then walks that list.  Software pipeline, unrolled by two (two alternating
         // register sets, no per-iteration moves): the parameters of the next listed entry are fetched from LDS while the
         // current one is evaluated.
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // deepest tiles are dispatched first
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + (int)(tid & 15);
-    const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + (int)(tid >> 4);
+    const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + tile_px(tid);   // wave = 8x8 block (gut_render_common.h)
+    const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + tile_py(tid);
     const bool inside = (px < v.width) && (py < v.height);
     const size_t pix = (size_t)py * (size_t)v.width + (size_t)px;
     const RayState ray = make_ray(v, ray_ori, ray_dir, pix, inside);
