@@ -1142,14 +1142,18 @@ float oracle_tile_min_power(float tx, float ty, const float* conic4, const float
 /* Layout study (tools only, not used by any test): for the traversal oracle_render performs, count the (wave, list entry) pairs
  * in which at least one of the wave's 64 pixels is hit, for two assignments of a 16x16 tile's pixels to four waves:
  * out[0] = 16x4 strips (wave = py_in_tile / 4), out[1] = 8x8 blocks (wave = (py_in_tile / 8) * 2 + px_in_tile / 8),
- * out[2] = hit (pixel, entry) pairs, out[3] = (tile, entry) pairs walked while any pixel of the tile was alive. */
+ * out[2] = hit (pixel, entry) pairs, out[3] = (tile, entry) pairs walked while any pixel of the tile was alive,
+ * out[4] / out[5] = (wave, entry) pairs in which the wave still had an alive ray (what it must at least look at without any
+ * per-wave culling), strips / blocks;  out[6] / out[7] = 8x8-block pairs whose particle's screen rectangle (proj_pos +- extent,
+ * optional) overlaps the block's pixel rectangle / the bounding rectangle of the block's ALIVE pixels — screen-space proxies for
+ * the static wedge test of the kernels and for one rebuilt from the alive rays of each wave. */
 void oracle_count_wave_pairs(const OracleParams* prm, const OracleCamera* cam, int W, int H, const float* density12,
                              const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                             uint64_t* out) {
+                             uint64_t* out, const float* proj_pos, const float* extent) {
     const PoseSet ps = make_pose_set(cam);
     const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
-    uint64_t c_strip = 0, c_block = 0, c_hits = 0, c_walk = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c_strip, c_block, c_hits, c_walk)
+    uint64_t c_strip = 0, c_block = 0, c_hits = 0, c_walk = 0, a_strip = 0, a_block = 0, r_static = 0, r_alive = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c_strip, c_block, c_hits, c_walk, a_strip, a_block, r_static, r_alive)
     for (int tile = 0; tile < gx * gy; ++tile) {
         const int tx = tile % gx, ty = tile / gx;
         const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
@@ -1173,9 +1177,17 @@ void oracle_count_wave_pairs(const OracleParams* prm, const OracleCamera* cam, i
             const float* g = density12 + (size_t)id * 12;
             float rows[3][3];
             quat_to_rows(g + 4, rows);
-            int strip[4] = {0, 0, 0, 0}, block[4] = {0, 0, 0, 0};
+            int strip[4] = {0, 0, 0, 0}, block[4] = {0, 0, 0, 0}, as[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+            int lo_x[4] = {99, 99, 99, 99}, hi_x[4] = {-1, -1, -1, -1}, lo_y[4] = {99, 99, 99, 99}, hi_y[4] = {-1, -1, -1, -1};
             for (int p = 0; p < 256; ++p) {
                 if (!alive[p]) continue;
+                as[(p >> 4) >> 2] = 1;
+                const int wb = ((p >> 4) >> 3) * 2 + ((p & 15) >> 3);
+                ab[wb] = 1;
+                if ((p & 15) < lo_x[wb]) lo_x[wb] = p & 15;
+                if ((p & 15) > hi_x[wb]) hi_x[wb] = p & 15;
+                if ((p >> 4) < lo_y[wb]) lo_y[wb] = p >> 4;
+                if ((p >> 4) > hi_y[wb]) hi_y[wb] = p >> 4;
                 Hit h;
                 eval_hit(prm, g, rows, &rays[p], &h);
                 if ((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold)) {
@@ -1186,8 +1198,19 @@ void oracle_count_wave_pairs(const OracleParams* prm, const OracleCamera* cam, i
                     if (T[p] < prm->min_transmittance) alive[p] = 0;
                 }
             }
-            for (int w = 0; w < 4; ++w) { c_strip += strip[w]; c_block += block[w]; }
+            for (int w = 0; w < 4; ++w) { c_strip += strip[w]; c_block += block[w]; a_strip += as[w]; a_block += ab[w]; }
+            if (proj_pos && extent) {
+                const float gx0 = proj_pos[2 * id] - extent[2 * id], gx1 = proj_pos[2 * id] + extent[2 * id];
+                const float gy0 = proj_pos[2 * id + 1] - extent[2 * id + 1], gy1 = proj_pos[2 * id + 1] + extent[2 * id + 1];
+                for (int w = 0; w < 4; ++w) {
+                    if (!ab[w]) continue;
+                    const float bx0 = tx * GUT_TILE + (w & 1) * 8, by0 = ty * GUT_TILE + (w >> 1) * 8;
+                    if (gx1 >= bx0 && gx0 <= bx0 + 8.0f && gy1 >= by0 && gy0 <= by0 + 8.0f) r_static++;
+                    const float ax0 = tx * GUT_TILE + lo_x[w], ax1 = tx * GUT_TILE + hi_x[w] + 1.0f, ay0 = ty * GUT_TILE + lo_y[w], ay1 = ty * GUT_TILE + hi_y[w] + 1.0f;
+                    if (gx1 >= ax0 && gx0 <= ax1 && gy1 >= ay0 && gy0 <= ay1) r_alive++;
+                }
+            }
         }
     }
-    out[0] = c_strip; out[1] = c_block; out[2] = c_hits; out[3] = c_walk;
+    out[0] = c_strip; out[1] = c_block; out[2] = c_hits; out[3] = c_walk; out[4] = a_strip; out[5] = a_block; out[6] = r_static; out[7] = r_alive;
 }
