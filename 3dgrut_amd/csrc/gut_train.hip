@@ -151,6 +151,10 @@ __device__ __forceinline__ void adam4(const AdamParams& ap, uint32_t c0, const f
 #undef GUT_ADAM_LANE
 }
 
+__device__ __forceinline__ bool all_zero(const float4& m, const float4& v) {
+    return m.x == 0.0f && m.y == 0.0f && m.z == 0.0f && m.w == 0.0f && v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f;
+}
+
 // adam4 with a zero gradient and the four learning rates handed over (bit-identical to adam4(ap, c0, 0, ...): the gradient
 // terms are exact zeros there too)
 __device__ __forceinline__ void adam4_zero_grad(const AdamParams& ap, const float4& lr, float4& p, float4& m, float4& v) {
@@ -324,20 +328,34 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         const unsigned long long mask = __ballot(mine);
         if (mask == 0ull) continue;  // wave-uniform
         if (mine) {
+            bool continue_row = false;
             // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
             // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
+            // A (p, m, v) group whose moments are all exactly zero — a Gaussian that never received a gradient — is a fixed point
+            // of the zero-gradient update (m' = v' = 0, p' = p - lr * 0 * rcp(eps) = p, bit for bit): nothing is written for it.
             float4 a = p12[3 * (size_t)i + 0], m = m12[3 * (size_t)i + 0], v = v12[3 * (size_t)i + 0];
-            adam4(a12, 0, zero, a, m, v);
-            p12[3 * (size_t)i + 0] = a; m12[3 * (size_t)i + 0] = m; v12[3 * (size_t)i + 0] = v;
+            bool moved = false;
+            if (!all_zero(m, v)) {
+                adam4(a12, 0, zero, a, m, v);
+                p12[3 * (size_t)i + 0] = a; m12[3 * (size_t)i + 0] = m; v12[3 * (size_t)i + 0] = v;
+                moved = true;
+            }
             float4 b = p12[3 * (size_t)i + 1];
             m = m12[3 * (size_t)i + 1]; v = v12[3 * (size_t)i + 1];
-            adam4(a12, 4, zero, b, m, v);
-            p12[3 * (size_t)i + 1] = b; m12[3 * (size_t)i + 1] = m; v12[3 * (size_t)i + 1] = v;
+            if (!all_zero(m, v)) {
+                adam4(a12, 4, zero, b, m, v);
+                p12[3 * (size_t)i + 1] = b; m12[3 * (size_t)i + 1] = m; v12[3 * (size_t)i + 1] = v;
+                moved = true;
+            }
             float4 c = p12[3 * (size_t)i + 2];
             m = m12[3 * (size_t)i + 2]; v = v12[3 * (size_t)i + 2];
-            adam4(a12, 8, zero, c, m, v);
-            p12[3 * (size_t)i + 2] = c; m12[3 * (size_t)i + 2] = m; v12[3 * (size_t)i + 2] = v;
-            if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
+            if (!all_zero(m, v)) {
+                adam4(a12, 8, zero, c, m, v);
+                p12[3 * (size_t)i + 2] = c; m12[3 * (size_t)i + 2] = m; v12[3 * (size_t)i + 2] = v;
+                moved = true;
+            }
+            if (!moved) continue_row = true;   // the activation row is already that of the unchanged raw row
+            if (act12 && !continue_row) activate_row(a, b, c, act12 + 3 * (size_t)i);
         }
         float4* bp = p48 + (size_t)wave_first * 12;
         float4* bm = m48 + (size_t)wave_first * 12;
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
             const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
             if (!((mask >> row) & 1ull)) continue;
             float4 pp = bp[q], mm = bm[q], vv = bv[q];
+            if (all_zero(mm, vv)) continue;  // fixed point of the update (see above): no store
             adam4_zero_grad(a48, s_lr48[col >> 2], pp, mm, vv);
             bp[q] = pp; bm[q] = mm; bv[q] = vv;
         }

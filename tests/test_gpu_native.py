@@ -225,6 +225,12 @@ def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
             coasting = early & ever_tiles
             assert int(coasting.sum()) > 0
             assert float((state(ovl)["raw"][coasting] - before[coasting]).abs().max()) > 0
+            # rows that never had a gradient are a fixed point of the update; the side-stream kernel writes nothing for them
+            dormant = early & ~ever_tiles
+            if k < 3:
+                assert int(dormant.sum()) > 0
+            assert torch.equal(state(ovl)["raw"][dormant], before[dormant])
+            assert not state(ovl)["m48"][dormant].any() and not state(ovl)["v12"][dormant].any()
         ever_tiles = (~early) if k == 0 else (ever_tiles | ~early)
         before = state(ovl)["raw"].clone()
     assert some_without_tiles > 1000

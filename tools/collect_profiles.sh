@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh'): rocprofv3 kernel statistics of the bench command and separate
-# PMC passes over two full native train steps of the bench scene (tools/fwd_once.py 6000000 2 step).  Every --pmc pass is its
+# PMC passes over ten full native train steps of the bench scene (tools/fwd_once.py 6000000 10 step).  Every --pmc pass is its
 # own rocprofv3 run with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE takes 3 and WRITE_SIZE 2 of the 4 TCC slots, SQ
 # has 8 slots, GRBM 2).  Results land under gpurun_out/profiles (scratch); tools/profile_report.py turns them into profiles/<round>/.
 set -o pipefail
@@ -15,7 +15,7 @@ timeout -k 10 300 python3 "$R/bench.py" --steps 20 --warmup 5 > "$OUT/bench_plai
 echo "plain bench done"
 pass() {  # name, counters...
     local name=$1; shift
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 "$R/tools/fwd_once.py" 6000000 2 step \
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 "$R/tools/fwd_once.py" 6000000 10 step \
         > "$OUT/pmc_$name.log" 2>&1 && echo "pmc pass $name done" || echo "pmc pass $name FAILED (see pmc_$name.log)"
 }
 pass FETCH_SIZE FETCH_SIZE

@@ -12,17 +12,25 @@ bwd = len(sys.argv) > 3 and sys.argv[3] == "bwd"
 step = len(sys.argv) > 3 and sys.argv[3] == "step"   # full native train steps (incl. the one-pass optimiser kernel)
 ro, rd = cams.pinhole_rays(W, H, fx, fx); K = cams.pinhole_intrinsics_dict(W, H, fx, fx)
 sc = scenes.scene_outdoor_like(n=n, seed=2)
-model = model_mod.GaussianModel(sc, device=dev)
+model = None if step else model_mod.GaussianModel(sc, device=dev)
 tr = gut.Tracer({"render": {"enable_kernel_timings": True}})
 b = gut.Batch(rays_ori=torch.as_tensor(ro, device=dev), rays_dir=torch.as_tensor(rd, device=dev),
               T_to_world=torch.as_tensor(cams.orbit_c2w(4.5, 7.0, 12.0), device=dev)[None], intrinsics_OpenCVPinholeCameraModelParameters=K)
 if step:
+    # the bench's own views and target, cycled as the bench cycles them, with the two-pass optimiser forced on (no probe): the
+    # LAST step's dispatches are the steady state the counters are read from (tools/profile_report.py)
+    import bench
     native = importlib.import_module("3dgrut_amd.native")
-    nm = native.NativeGaussianModel(sc, device=dev, spatial_order=True)   # the bench's default storage order (two-pass optimiser on)
-    ts = native.NativeTrainStep(nm, tr, scene_extent=5.0)
-    b.T_to_world = b.T_to_world.cpu()
+    fn, kw, W, H, fx, radius, elev, extent = bench.WORKLOADS["bicycle_like_6M_1237x822"]
+    sc = getattr(scenes, fn)(**dict(kw, n=n))
+    nm = native.NativeGaussianModel(sc, device=dev, spatial_order=True)
+    ts = native.NativeTrainStep(nm, tr, scene_extent=extent, overlap_optimizer=True)
+    b.intrinsics_OpenCVPinholeCameraModelParameters = cams.pinhole_intrinsics_dict(W, H, fx, fx)
+    ro, rd, c2ws = bench.make_views(cams, 8, W, H, fx, radius, elev, False)
+    b.rays_ori, b.rays_dir = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
     b.rgb_gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(1)).to(dev)
-    for _ in range(iters):
+    for k in range(iters):
+        b.T_to_world = torch.as_tensor(c2ws[k % 8])[None]
         ts.step(b)
 for _ in range(0 if step else iters):
     if bwd:

@@ -24,12 +24,17 @@ def key_of(name):
     return None
 
 
+PMC_STEPS = 10   # tools/collect_profiles.sh: fwd_once.py 6000000 10 step
+
+
 def _second_half(rows_by_name):
-    """fwd_once runs two train steps: keep each kernel's dispatches of the LAST step (the first dispatch of a kernel with a
-    spill area — K6 — can include the runtime's one-off scratch set-up, 0.54 -> 1.45 ms)."""
+    """fwd_once runs PMC_STEPS train steps over the bench's views: keep each kernel's dispatches of the LAST step — the steady
+    state (every view seen once, so the Adam moments of the rows are what they are in the bench; and the first dispatch of a
+    kernel with a spill area — K6 — can include the runtime's one-off scratch set-up, 0.54 -> 1.45 ms)."""
     out = []
     for rows in rows_by_name.values():
-        out.extend(rows[len(rows) // 2:])
+        per_step = max(1, len(rows) // PMC_STEPS)
+        out.extend(rows[-per_step:] if len(rows) >= PMC_STEPS else rows[len(rows) // 2:])
     return out
 
 
@@ -67,8 +72,8 @@ shutil.copy(stats[0], os.path.join(dst, "bench_kernel_stats.csv"))
 for f in ("bench_under_rocprof.json", "bench_plain.json"):
     shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 
-traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over tools/fwd_once.py 6000000 2 step (two full "
-                   "native train steps, bicycle-like stand-in, 1 MI355X), mean per launch.  FETCH_SIZE/WRITE_SIZE are in KiB.  Per "
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over tools/fwd_once.py 6000000 10 step (ten full "
+                   "native train steps over the bench views, two-pass optimiser forced on, bicycle-like stand-in, 1 MI355X), last step, mean per launch.  FETCH_SIZE/WRITE_SIZE are in KiB.  Per "
                    "MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half of the bytes of wide (16 B/lane) streaming reads: "
                    "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024.  The factor 2 is calibrated for 16 B/lane streams only; for the "
                    "gather-heavy kernels (render, render_bwd: 48-byte row gathers) hbm_bytes_uncorrected = (FETCH+WRITE)*1024 is the "
@@ -84,8 +89,8 @@ for k, d in traffic["kernels"].items():
     d["hbm_bytes_uncorrected"] = (f + w) * 1024
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
-sq = {"note": "separate rocprofv3 --pmc passes (SQ_A, SQ_B, TCC) over tools/fwd_once.py 6000000 2 step, mean per launch, values summed over "
-              "the chip as rocprofv3 reports them.  duration_ms is the kernel-trace duration in the SAME (profiled) pass; every figure is the mean over the dispatches of the second of the two steps.  "
+sq = {"note": "separate rocprofv3 --pmc passes (SQ_A, SQ_B, TCC) over tools/fwd_once.py 6000000 10 step, mean per launch, values summed over "
+              "the chip as rocprofv3 reports them.  duration_ms is the kernel-trace duration in the SAME (profiled) pass; every figure is the mean over the dispatches of the last of the ten steps.  "
               f"valu_issue_frac = SQ_INSTS_VALU x {VALU_ISSUE_NS} ns / ({SIMDS} SIMDs x duration): share of the chip's measured wave64 VALU "
               "issue rate (tools/pk_rate.hip) the kernel's vector instructions account for.  valu_active_frac = 4 x SQ_ACTIVE_INST_VALU / "
               "({SIMDS} SIMDs x GRBM_GUI_ACTIVE / 8): SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles, GRBM_GUI_ACTIVE is summed "
@@ -129,7 +134,7 @@ L = ["# Profiles (" + rnd + ")\n",
      "under the profiler), `bench_plain.json` (same command without the profiler, same box), `pmc_traffic.json` (HBM bytes per launch "
      "from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes), `pmc_sq.json` (SQ / TCC / GRBM counters per launch from three more "
      "separate `--pmc` passes, with the derived VALU fractions; formulas in its `note`).  All PMC passes run "
-     "`tools/fwd_once.py 6000000 2 step` (two full native train steps of the bench scene).\n",
+     "`tools/fwd_once.py 6000000 10 step` (ten full native train steps over the bench's 8 views, two-pass optimiser forced on of the bench scene).\n",
      f"Bench line (plain): **{plain['value']:.1f} images/s, {plain['ms_per_step']:.3f} ms/step**, forward render "
      f"{plain['render_ms_per_frame']:.3f} ms/frame; under the profiler {prof['value']:.1f} images/s.  Phases (HIP events, ms): "
      + ", ".join(f"{k} {v:.3f}" for k, v in plain["phase_ms"].items()) + ".\n",
