@@ -151,7 +151,9 @@ for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimize
     L.append(f"| {k} | {g(e, 'duration_ms_SQ_A', '{:.3f}')} | {g(t, 'hbm_bytes', '{:.3e}')} | {g(t, 'hbm_bytes_uncorrected', '{:.3e}')} | "
              f"{g(e, 'SQ_INSTS_VALU', '{:.3e}')} | {g(e, 'valu_issue_frac', '{:.2f}')} | {g(e, 'valu_active_frac', '{:.2f}')} | "
              f"{g(e, 'SQ_INSTS_LDS', '{:.3e}')} | {g(e, 'SQ_LDS_BANK_CONFLICT', '{:.3e}')} | {g(e, 'atomic_GBps', '{:.0f}')} |")
-L += ["", "Top kernels (all launches of the run: 25 train steps + 10 render-only frames + setup):\n",
+L += ["", "`optimizer_early` is launched twice per step (25 % / 75 % of the row blocks): its row is the mean of the two launches, "
+          "double it for the per-step total.  In this steady state it writes nothing for rows whose moments are still exactly zero.",
+      "", "Top kernels (all launches of the run: 25 train steps + 10 render-only frames + setup):\n",
       "| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|"]
 for r in rows[:18]:
     L.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
