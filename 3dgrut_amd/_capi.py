@@ -16,6 +16,8 @@ BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
 BWD_SKIP_EPILOGUE = 4
 OPT_LAZY_TILE_ORDER = 1
+ADAM_CLEAR_CONSUMED_GRADS = 1
+GRADIENT_RECORD_FLOATS = 16
 OPT_SORTED_REFERENCE_BACKWARD = 2
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer",
                       "optimizer_early")
@@ -63,7 +65,8 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
            "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
-           "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
+           "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_compact_gradient_rows", "gut_scatter_gradient_records",
+           "gut_sh_adam_step_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
 
 _lib = None
 
@@ -117,6 +120,9 @@ def load():
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
                                      C.c_float, C.c_float, C.c_float, u32, vp, vp, u32]
+    lib.gut_sh_adam_step_ex.argtypes = lib.gut_sh_adam_step.argtypes + [u32]
+    lib.gut_compact_gradient_rows.argtypes = [vp, vp, vp, vp, u32, vp]
+    lib.gut_scatter_gradient_records.argtypes = [vp, vp, u32, u32, vp, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
     _lib = lib

@@ -752,6 +752,27 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     return 0;
 }
 
+int gut_compact_gradient_rows(gut_handle h, void* stream_, const float* d_particle_density, float* d_records, uint32_t capacity,
+                              uint32_t* d_count) {
+    if (!h) return fail("gut_compact_gradient_rows: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (!h->have_backward || h->fwd_stream != s)
+        return fail("gut_compact_gradient_rows: no backward context on this stream (call gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) first)");
+    if (h->early_ran) return fail("gut_compact_gradient_rows: cannot follow gut_optimize_rows_without_gradient");
+    if (!d_count || (h->n && (!d_particle_density || !d_records))) return fail("gut_compact_gradient_rows: null pointer argument");
+    if (capacity < h->n) return fail("gut_compact_gradient_rows: the record buffer must hold one record per particle");
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+    gut::launch_compact_gradient_rows(s, h->n, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
+                                      h->grad16.as<float>(), d_records, capacity, d_count);
+    HIP_TRY(hipGetLastError());
+    h->have_backward = false;  // the gradient rows are consumed ...
+    h->grad16_zero = true;     // ... and left zero by the kernel
+    return 0;
+}
+
 int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48,
                                        float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
                                        float eps, uint32_t step, float* d_act12_out) {

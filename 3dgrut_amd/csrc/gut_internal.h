@@ -96,6 +96,8 @@ void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
                                  float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only);
 // Adam step of the rows that get no gradient this iteration (tiles_count == 0), see k_adam_rows_without_gradient
+void launch_compact_gradient_rows(hipStream_t s, uint32_t n, const float* act12, const uint32_t* tiles_count, const float* feat,
+                                  float* grad16, float* records, uint32_t capacity, uint32_t* count);
 void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t* tiles_count, float* raw12, float* raw_m, float* raw_v,
                                        float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* act12_out,

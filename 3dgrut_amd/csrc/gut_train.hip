@@ -102,6 +102,8 @@ struct ShAdamParams {
     int32_t sh_degree;
     float grad_scale;
     int32_t rows_with_tiles_only;  // kScratch: rows with tiles_count == 0 were already updated by k_adam_rows_without_gradient
+    int32_t clear_consumed;        // !kScratch: gradient rows that were non-zero are written back as zeros (sparse exchange: the
+                                   // dense accumulators are only ever touched where a record landed, never cleared wholesale)
 };
 
 __device__ __forceinline__ void sh_basis_fast(int deg, float x, float y, float z, float Y[16]) {
@@ -174,7 +176,7 @@ __device__ __forceinline__ void adam4_zero_grad(const AdamParams& ap, const floa
 // are chained to the raw parameters here (the activations are recomputed from the raw row the optimiser loads anyway, with
 // the very function that produced the forward's inputs), and the masked dL/dRGB never leaves registers.
 template <bool kScratch>
-__global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float* __restrict__ mrgb,
+__global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __restrict__ mrgb,
                                                    float4* __restrict__ grad12, float4* __restrict__ p12,
                                                    float4* __restrict__ m12, float4* __restrict__ v12, float4* __restrict__ p48,
                                                    float4* __restrict__ m48, float4* __restrict__ v48,
@@ -228,6 +230,11 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
                 }
             } else {
                 g0 = grad12[3 * (size_t)i + 0]; g1 = grad12[3 * (size_t)i + 1]; g2 = grad12[3 * (size_t)i + 2];
+                if (sp.clear_consumed && !(all_zero(g0, g1) && g2.x == 0.0f && g2.y == 0.0f && g2.z == 0.0f)) {
+                    grad12[3 * (size_t)i + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    grad12[3 * (size_t)i + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    grad12[3 * (size_t)i + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             g0.x *= gs; g0.y *= gs; g0.z *= gs; g0.w *= gs; g1.x *= gs; g1.y *= gs; g1.z *= gs; g1.w *= gs;
             g2.x *= gs; g2.y *= gs; g2.z *= gs; g2.w = 0.0f;
@@ -248,8 +255,10 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, const float
                 if (kScratch) {
                     r = own_r * sp.grad_scale; g = own_g * sp.grad_scale; bl = own_b * sp.grad_scale;
                 } else {
-                    const float* mr = mrgb + ((size_t)vw * sp.view_stride + i) * 3;
-                    r = mr[0] * sp.grad_scale; g = mr[1] * sp.grad_scale; bl = mr[2] * sp.grad_scale;
+                    float* mr = mrgb + ((size_t)vw * sp.view_stride + i) * 3;
+                    r = mr[0]; g = mr[1]; bl = mr[2];
+                    if (sp.clear_consumed && !(r == 0.0f && g == 0.0f && bl == 0.0f)) { mr[0] = 0.0f; mr[1] = 0.0f; mr[2] = 0.0f; }
+                    r *= sp.grad_scale; g *= sp.grad_scale; bl *= sp.grad_scale;
                 }
                 if (r == 0.0f && g == 0.0f && bl == 0.0f) continue;
                 const float dx = px - sp.cam[3 * vw + 0], dy = py - sp.cam[3 * vw + 1], dz = pz - sp.cam[3 * vw + 2];
@@ -374,6 +383,88 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sparse gradient exchange of the data-parallel trainer.  A view gives a gradient only to the Gaussians its rays hit, a
+// small share of the scene, so what crosses xGMI per view is a list of 64-byte RECORDS
+//     [ d pos3 | d density logit | d quat4 (un-normalised) | d log-scale3 | row id (uint bits) | masked dL/dRGB 3 | 0 ]
+// (the [N,12] gradient already chained to the RAW parameters, and the generator of the SH gradient — see K8c), one per
+// Gaussian whose renderer gradient row is non-zero, instead of dense [N,12] + [N,3] tensors.
+//   k_compact_gradient_rows    : renderer rows (gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE)) -> records, consumed rows zeroed
+//   k_scatter_gradient_records : one view's records -> += dense raw-gradient accumulator, = that view's [N,3] dL/dRGB slab
+// Every id occurs at most once per view and the views are scattered one launch after the other in rank order, so the sums
+// are formed in the same order on every rank: the replicas stay bit-identical.  The dense targets are zero everywhere except
+// where records landed, and k_sh_adam<false>(clear_consumed) zeroes exactly those again.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool any_bits(const float4& a) {
+    return ((__float_as_uint(a.x) | __float_as_uint(a.y) | __float_as_uint(a.z) | __float_as_uint(a.w)) & 0x7fffffffu) != 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_compact_gradient_rows(uint32_t n, const float4* __restrict__ act12,
+                                                                 const uint32_t* __restrict__ tiles_count,
+                                                                 const float* __restrict__ feat, float4* __restrict__ grad16,
+                                                                 float4* __restrict__ records, uint32_t capacity,
+                                                                 uint32_t* __restrict__ count) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    float4 g0, g1, g2, g3;
+    bool have = false;
+    if (i < n && tiles_count[i] != 0) {
+        g0 = grad16[4 * (size_t)i + 0];
+        g1 = grad16[4 * (size_t)i + 1];
+        g2 = grad16[4 * (size_t)i + 2];
+        g3 = grad16[4 * (size_t)i + 3];
+        have = any_bits(g0) || any_bits(g1) || any_bits(g2) || any_bits(g3);
+    }
+    const unsigned long long bal = __ballot(have);
+    if (bal == 0ull) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(bal));
+    base = __shfl(base, 0);
+    const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (!have || slot >= capacity) return;  // (capacity is the number of Gaussians: never exceeded)
+    const float m0 = feat[3 * (size_t)i + 0] > 0.0f ? g2.w : 0.0f;
+    const float m1 = feat[3 * (size_t)i + 1] > 0.0f ? g3.x : 0.0f;
+    const float m2 = feat[3 * (size_t)i + 2] > 0.0f ? g3.y : 0.0f;
+    const float4 a = act12[3 * (size_t)i], qn = act12[3 * (size_t)i + 1], sc = act12[3 * (size_t)i + 2];
+    g0.w = g0.w * a.w * (1.0f - a.w);                                               // sigmoid
+    const float dot = g1.x * qn.x + g1.y * qn.y + g1.z * qn.z + g1.w * qn.w;
+    const float inv = 1.0f / sc.w;                                                  // 1 / |quat| (pad column of the activated row)
+    g1 = make_float4((g1.x - qn.x * dot) * inv, (g1.y - qn.y * dot) * inv, (g1.z - qn.z * dot) * inv, (g1.w - qn.w * dot) * inv);
+    records[4 * (size_t)slot + 0] = g0;
+    records[4 * (size_t)slot + 1] = g1;
+    records[4 * (size_t)slot + 2] = make_float4(g2.x * sc.x, g2.y * sc.y, g2.z * sc.z, __uint_as_float(i));   // exp
+    records[4 * (size_t)slot + 3] = make_float4(m0, m1, m2, 0.0f);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    grad16[4 * (size_t)i + 0] = z; grad16[4 * (size_t)i + 1] = z; grad16[4 * (size_t)i + 2] = z; grad16[4 * (size_t)i + 3] = z;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter_gradient_records(const float4* __restrict__ records, uint32_t count, uint32_t n,
+                                                                    float4* __restrict__ grad12, float* __restrict__ mrgb_view) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= count) return;
+    const float4 g0 = records[4 * (size_t)r + 0], g1 = records[4 * (size_t)r + 1], g2 = records[4 * (size_t)r + 2];
+    const float4 m = records[4 * (size_t)r + 3];
+    const uint32_t id = __float_as_uint(g2.w);
+    if (id >= n) return;  // not a row of this model: a corrupt record must not become a wild store
+    float4 t = grad12[3 * (size_t)id + 0];
+    grad12[3 * (size_t)id + 0] = make_float4(t.x + g0.x, t.y + g0.y, t.z + g0.z, t.w + g0.w);
+    t = grad12[3 * (size_t)id + 1];
+    grad12[3 * (size_t)id + 1] = make_float4(t.x + g1.x, t.y + g1.y, t.z + g1.z, t.w + g1.w);
+    t = grad12[3 * (size_t)id + 2];
+    grad12[3 * (size_t)id + 2] = make_float4(t.x + g2.x, t.y + g2.y, t.z + g2.z, 0.0f);
+    mrgb_view[3 * (size_t)id + 0] = m.x;
+    mrgb_view[3 * (size_t)id + 1] = m.y;
+    mrgb_view[3 * (size_t)id + 2] = m.z;
+}
+
+void launch_compact_gradient_rows(hipStream_t s, uint32_t n, const float* act12, const uint32_t* tiles_count, const float* feat,
+                                  float* grad16, float* records, uint32_t capacity, uint32_t* count) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_compact_gradient_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n,
+                       reinterpret_cast<const float4*>(act12), tiles_count, feat, reinterpret_cast<float4*>(grad16),
+                       reinterpret_cast<float4*>(records), capacity, count);
+}
+
 }  // namespace gut
 
 // AdamParams for the adam4 kernels: lr[] already holds lr / (1 - beta1^t) and bias2_sqrt holds 1 / sqrt(1 - beta2^t)
@@ -398,11 +489,12 @@ void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const
     if (n == 0) return;
     ShAdamParams sp;
     sp.rows_with_tiles_only = rows_with_tiles_only ? 1 : 0;
+    sp.clear_consumed = 0;
     fill_adam(sp.a12, lr12, 12, beta1, beta2, eps, step);
     fill_adam(sp.a48, lr48, 48, beta1, beta2, eps, step);
     sp.cam = d_camera_position;
     sp.n = n; sp.views = 1; sp.sh_degree = sh_degree; sp.grad_scale = 1.0f; sp.view_stride = n;
-    hipLaunchKernelGGL(k_sh_adam<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sp, (const float*)nullptr,
+    hipLaunchKernelGGL(k_sh_adam<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sp, (float*)nullptr,
                        reinterpret_cast<float4*>(grad16), reinterpret_cast<float4*>(raw12), reinterpret_cast<float4*>(raw_m),
                        reinterpret_cast<float4*>(raw_v), reinterpret_cast<float4*>(sh48), reinterpret_cast<float4*>(sh_m),
                        reinterpret_cast<float4*>(sh_v), visibility, reinterpret_cast<float4*>(act12_out), tiles_count, feat);
@@ -489,28 +581,51 @@ int gut_mcmc_relocation(void* stream, int32_t n, const float* d_opacities, const
 }
 
 
-int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* d_camera_positions,
-                     const float* d_mrgb, const float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
-                     float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
-                     float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out,
-                     uint32_t mrgb_view_stride) {
+int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* d_camera_positions,
+                        float* d_mrgb, float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
+                        float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                        float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out,
+                        uint32_t mrgb_view_stride, uint32_t flags) {
     if (num_particles == 0) return 0;
     if (!d_camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
         !lr12 || !lr48)
         return 1;
     if (num_views == 0 || num_views > 1024 || sh_degree < 0 || sh_degree > 3) return 3;
+    if (flags & ~(uint32_t)GUT_ADAM_CLEAR_CONSUMED_GRADS) return 3;
     gut::ShAdamParams sp;
     fill_adam(sp.a12, lr12, 12, beta1, beta2, eps, step);
     fill_adam(sp.a48, lr48, 48, beta1, beta2, eps, step);
     sp.cam = d_camera_positions;
     sp.n = num_particles; sp.views = num_views; sp.sh_degree = sh_degree; sp.grad_scale = grad_scale;
     sp.view_stride = mrgb_view_stride ? mrgb_view_stride : num_particles;
+    sp.rows_with_tiles_only = 0;
+    sp.clear_consumed = (flags & GUT_ADAM_CLEAR_CONSUMED_GRADS) ? 1 : 0;
     if (sp.view_stride < num_particles) return 3;
     hipLaunchKernelGGL(gut::k_sh_adam<false>, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
-                       static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<float4*>(const_cast<float*>(d_raw_grad12)),
+                       static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<float4*>(d_raw_grad12),
                        reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v),
                        reinterpret_cast<float4*>(d_sh48), reinterpret_cast<float4*>(d_sh_m), reinterpret_cast<float4*>(d_sh_v),
                        d_visibility, reinterpret_cast<float4*>(d_act12_out), (const uint32_t*)nullptr, (const float*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views, const float* d_camera_positions,
+                     const float* d_mrgb, const float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
+                     float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                     float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out,
+                     uint32_t mrgb_view_stride) {
+    return gut_sh_adam_step_ex(stream, num_particles, sh_degree, num_views, d_camera_positions, const_cast<float*>(d_mrgb),
+                               const_cast<float*>(d_raw_grad12), grad_scale, d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12,
+                               lr48, beta1, beta2, eps, step, d_visibility, d_act12_out, mrgb_view_stride, 0u);
+}
+
+int gut_scatter_gradient_records(void* stream, const float* d_records, uint32_t count, uint32_t num_particles, float* d_raw_grad12,
+                                 float* d_mrgb_view) {
+    if (count == 0) return 0;
+    if (!d_records || !d_raw_grad12 || !d_mrgb_view) return 1;
+    hipLaunchKernelGGL(gut::k_scatter_gradient_records, dim3((count + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(d_records), count, num_particles,
+                       reinterpret_cast<float4*>(d_raw_grad12), d_mrgb_view);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

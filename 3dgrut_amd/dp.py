@@ -109,3 +109,36 @@ def allgather_rows_async(out, local, world: int, group=None):
         allgather_rows_(out, local, world, group)
         return _Done()
     return dist.all_gather_into_tensor(out, local, group=group, async_op=True)
+
+
+def exchange_gradient_records(records, count, world: int, scratch: dict, group=None):
+    """Sparse gradient exchange: every rank contributes the first `count` rows of its `records` [capacity, 16] tensor (one
+    64-byte record per Gaussian the rank's view gave a gradient to, gut_compact_gradient_rows).  Returns (gathered, counts):
+    gathered[r, :counts[r]] are rank r's records, identical on every rank.  Two collectives: the W counts (then ONE host
+    read-back, which sizes the payload), and an all-gather of max(counts) records per rank — what crosses xGMI scales with
+    the Gaussians the views actually touched, not with the size of the scene.
+    `scratch` keeps the receive buffer between steps (grown on demand).  `count`: one-element integer tensor on records' device."""
+    dev = records.device
+    if _skip(world):
+        c = int(count.item())
+        return records[None, :c], [c]
+    cnt = count.to(torch.int64).reshape(1)
+    if _stage_on_cpu(cnt, group) or not cnt.is_cuda:
+        parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, cnt.cpu(), group=group)
+        counts = [int(p.item()) for p in parts]
+    else:
+        allc = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, cnt, group=group)
+        counts = [int(x) for x in allc.cpu().tolist()]
+    maxc = max(counts)
+    width = records.shape[1]
+    need = world * max(maxc, 1) * width
+    flat = scratch.get("flat")
+    if flat is None or flat.numel() < need or flat.device != dev:
+        flat = torch.empty(int(need * 1.25) + width, dtype=records.dtype, device=dev)
+        scratch["flat"] = flat
+    gathered = flat[:world * maxc * width].view(world, maxc, width)
+    if maxc:
+        allgather_rows_(gathered, records[:maxc], world, group)
+    return gathered, counts

@@ -296,6 +296,18 @@ class SplatRaster:
                 int(step), None if act_out is None else act_out.data_ptr())
         _capi.check(rc, "optimize_rows_without_gradient")
 
+    def compact_gradient_rows(self, act12, records, count):
+        """Per-Gaussian epilogue of trace_bwd(..., skip_epilogue=True) as a LIST: one 64-byte record per Gaussian with a
+        non-zero gradient row (gut_compact_gradient_rows; layout in gut_hip.h).  records: float32 [>= N, 16] on the device,
+        count: int32/uint32 device tensor with one element (receives the number of records)."""
+        if records.shape[0] < act12.shape[0] or records.shape[1] != _capi.GRADIENT_RECORD_FLOATS or not records.is_contiguous():
+            raise ValueError("records must be a contiguous [>= num_particles, 16] float32 tensor")
+        stream = torch.cuda.current_stream(act12.device).cuda_stream
+        with torch.cuda.device(act12.device):
+            rc = self._lib.gut_compact_gradient_rows(self._handle, C.c_void_p(stream), act12.data_ptr(), records.data_ptr(),
+                                                     int(records.shape[0]), count.data_ptr())
+        _capi.check(rc, "compact_gradient_rows")
+
     def collect_times(self):
         f, b = C.c_float(-1.0), C.c_float(-1.0)
         _capi.check(self._lib.gut_collect_times(self._handle, C.byref(f), C.byref(b)), "collect_times")

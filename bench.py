@@ -244,7 +244,8 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
         model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree, spatial_order=not args.scene_order)
         stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
                                              rank=rank, fused_sh_adam=not args.dense_exchange,
-                                             overlap_optimizer=False if args.no_overlap_optimizer else None)
+                                             overlap_optimizer=False if args.no_overlap_optimizer else None,
+                                             dp_exchange=args.dp_exchange)
     else:
         model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
         stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
@@ -322,6 +323,9 @@ def main():
                     help="native: fused HIP activation/Adam around the renderer; autograd: torch.autograd + torch.optim.Adam")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="native trainer: materialise the [N,48] SH gradient and all-reduce it (default: compact exchange + fused SH-grad/Adam)")
+    ap.add_argument("--dp-exchange", default="sparse", choices=["sparse", "dense"],
+                    help="N>1 (native trainer, compact exchange): sparse = 64-byte records of the Gaussians each view gave a gradient "
+                         "to (all-gather of max-count records per rank); dense = all-reduce [N,12] + all-gather [N,3] per view")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: initialise RCCL with world size 1 and issue the data-parallel collectives anyway "
                          "(exercises the N>1 call sequence on a one-GPU box; the number is NOT a bench line)")
@@ -439,7 +443,8 @@ def main():
             "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, host-staged exchange - not a bench line)"
                                                       if os.environ.get("GUT_BENCH_SHARE_GPU") == "1" else ""),
             "config": {"workload": args.workload, "num_gaussians": int(stats["num_particles"]), "resolution": [W, H],
-                       "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}" + ("" if world == 1 else (" dense all-reduce [N,60]" if (args.dense_exchange or args.trainer != "native") else " all-reduce [N,12] + all-gather [N,3]")),
+                       "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}" + ("" if world == 1 else (" dense all-reduce [N,60]" if (args.dense_exchange or args.trainer != "native") else (" sparse exchange: all-gather of 64-byte gradient records" if args.dp_exchange == "sparse" else " all-reduce [N,12] + all-gather [N,3]"))),
+                       "exchanged_records_last_step": getattr(stepper, "exchanged_records", None),
                        "loss": "0.8*L1+0.2*(1-SSIM) (HIP fused SSIM)",
                        "optimizer": (("HIP fused SH-gradient+Adam" if not args.dense_exchange else "HIP fused Adam") if args.trainer == "native" else "torch.optim.Adam(fused)") +
                                     (" selective(visibility)" if args.selective_adam else "") + ", all 59 params/Gaussian",

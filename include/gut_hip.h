@@ -277,6 +277,35 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream, float* d_raw1
                                        float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* d_act12_out);
 
+/* ---- Sparse gradient exchange of the data-parallel trainer (new functionality, the reference is single-GPU) ----
+ * A view gives a gradient only to the Gaussians its rays hit.  Instead of dense [N,12] + [N,3] tensors per view, the ranks
+ * exchange lists of 64-byte records, one per Gaussian with a non-zero gradient row:
+ *     f32[16] = { d pos3, d density logit, d quat4 (un-normalised), d log-scale3, row id (uint32 bits), masked dL/dRGB 3, 0 }
+ * (the gradient w.r.t. the RAW parameters, as GUT_BWD_RAW_PARAMETER_GRADS | GUT_BWD_COMPACT_RADIANCE_GRADS would write it).
+ *
+ * gut_compact_gradient_rows: epilogue of the last gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE).  d_particle_density: the
+ *   activated rows the forward was given (gut_activate_pack layout).  d_records: [capacity,16] with capacity >= num_particles
+ *   (so it cannot overflow); *d_count (device uint32) receives the number of records.  Record order is unspecified; every
+ *   row id occurs at most once.  Consumes the backward context (the handle's gradient rows are left zero).
+ * gut_scatter_gradient_records: adds `count` records of ONE view into the dense accumulator d_raw_grad12 [N,12] and stores
+ *   their dL/dRGB into that view's slab d_mrgb_view [N,3].  Both must be zero wherever no record lands (allocate zeroed once;
+ *   gut_sh_adam_step_ex(..., GUT_ADAM_CLEAR_CONSUMED_GRADS) zeroes what it consumed).  Scatter the views one call after the
+ *   other in the same order on every rank: the sums are then formed in the same order everywhere and replicas stay
+ *   bit-identical.
+ * gut_sh_adam_step_ex: gut_sh_adam_step with flags; GUT_ADAM_CLEAR_CONSUMED_GRADS writes zeros over every non-zero row of
+ *   d_raw_grad12 / d_mrgb it read. */
+#define GUT_ADAM_CLEAR_CONSUMED_GRADS 1u
+#define GUT_GRADIENT_RECORD_FLOATS 16
+int gut_compact_gradient_rows(gut_handle h, void* stream, const float* d_particle_density, float* d_records, uint32_t capacity,
+                              uint32_t* d_count);
+int gut_scatter_gradient_records(void* stream, const float* d_records, uint32_t count, uint32_t num_particles, float* d_raw_grad12,
+                                 float* d_mrgb_view);
+int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views,
+                        const float* d_camera_positions, float* d_mrgb, float* d_raw_grad12, float grad_scale,
+                        float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
+                        const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
+                        const float* d_visibility, float* d_act12_out, uint32_t mrgb_view_stride, uint32_t flags);
+
 /* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */
 int gut_mcmc_relocation(void* stream, int32_t n, const float* d_opacities, const float* d_scales, const int32_t* d_ratios,

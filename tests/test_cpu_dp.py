@@ -50,3 +50,36 @@ def test_single_rank_is_a_no_op():
     t = torch.ones(4)
     dp.allreduce_mean_([t], 1)
     assert torch.equal(t, torch.ones(4)) and dp.view_index(5, 0, 1, 4) == 1
+
+
+def _records_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scratch = {}
+    outs = []
+    for step, counts in enumerate([(5, 40, 0), (0, 0, 0), (300, 7, 12)]):   # ragged, all empty, receive buffer regrown
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        rec = torch.randn((300, 16), generator=g)          # capacity = "number of Gaussians"; rows beyond the count are stale
+        gathered, got = dp.exchange_gradient_records(rec, torch.tensor([counts[rank]], dtype=torch.int32), world, scratch)
+        outs.append(dict(counts=got, rows=[gathered[r, :got[r]].clone() for r in range(world)], mine=rec[:counts[rank]].clone()))
+    torch.save(outs, os.path.join(out_dir, f"rec{rank}.pt"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_three_rank_sparse_record_exchange(tmp_path):
+    """exchange_gradient_records: every rank ends with every rank's records (ragged counts, zero counts), bit-identical."""
+    world = 3
+    mp.spawn(_records_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rec{k}.pt")) for k in range(world)]
+    for step, counts in enumerate([(5, 40, 0), (0, 0, 0), (300, 7, 12)]):
+        for k in range(world):
+            assert r[k][step]["counts"] == list(counts)
+            for src in range(world):
+                assert r[k][step]["rows"][src].shape == (counts[src], 16)
+                assert torch.equal(r[k][step]["rows"][src], r[src][step]["mine"])
+
+
+def test_single_rank_record_exchange_is_a_view():
+    rec = torch.arange(64.0).reshape(4, 16)
+    gathered, counts = dp.exchange_gradient_records(rec, torch.tensor([3], dtype=torch.int32), 1, {})
+    assert counts == [3] and gathered.shape == (1, 3, 16) and gathered.data_ptr() == rec.data_ptr()

@@ -26,7 +26,7 @@ def _gt(k):
     return torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(10 + k)).to(DEV)
 
 
-def _worker(rank, world, port, out_dir, fused, chunks=1):
+def _worker(rank, world, port, out_dir, fused, chunks=1, exchange="dense"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     gut = importlib.import_module("3dgrut_amd"); native = importlib.import_module("3dgrut_amd.native")
@@ -34,14 +34,19 @@ def _worker(rank, world, port, out_dir, fused, chunks=1):
     sc = scenes.scene_c1(600, 31)
     model = native.NativeGaussianModel(sc, device=DEV)
     stepper = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, world_size=world, rank=rank,
-                                     fused_sh_adam=fused, dp_chunks=chunks, dp_chunk_min_rows=1)
+                                     fused_sh_adam=fused, dp_chunks=chunks, dp_chunk_min_rows=1, dp_exchange=exchange)
     if fused:
         assert len(stepper.chunks) == chunks
+    received = []
     view = _views()[rank]
     batch = to_batch(view, DEV); batch.rgb_gt = _gt(rank)
     for _ in range(2):
         stepper.step(batch)
-    torch.save(dict(raw=model.raw.cpu(), feats=model.features.cpu()), os.path.join(out_dir, f"r{rank}.pt"))
+        received.append(getattr(stepper, "exchanged_records", -1))
+    clean = True
+    if fused and exchange == "sparse":   # the dense accumulators are left zero by the optimiser kernel
+        clean = not bool(stepper.g12.any()) and not bool(stepper.mrgb[0].any())
+    torch.save(dict(raw=model.raw.cpu(), feats=model.features.cpu(), received=received, clean=clean), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -49,12 +54,16 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("fused,chunks", [(True, 1), (True, 3), (False, 1)])
-def test_two_rank_native_step_equals_mean_of_views(tmp_path, fused, chunks):
-    """chunks = 3: the exchange + optimiser pipeline over row chunks of the Gaussians (600 rows -> 256 + 256 + 88)."""
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), fused, chunks), nprocs=2, join=True)
+@pytest.mark.parametrize("fused,chunks,exchange", [(True, 1, "dense"), (True, 3, "dense"), (True, 1, "sparse"), (False, 1, "dense")])
+def test_two_rank_native_step_equals_mean_of_views(tmp_path, fused, chunks, exchange):
+    """chunks = 3: the exchange + optimiser pipeline over row chunks of the Gaussians (600 rows -> 256 + 256 + 88).
+    exchange = sparse: 64-byte records of the Gaussians each view gave a gradient to instead of dense per-view tensors."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), fused, chunks, exchange), nprocs=2, join=True)
     r = [torch.load(os.path.join(tmp_path, f"r{k}.pt")) for k in range(2)]
     assert torch.equal(r[0]["raw"], r[1]["raw"]) and torch.equal(r[0]["feats"], r[1]["feats"])  # replicas stay identical
+    if exchange == "sparse":
+        assert r[0]["clean"] and r[1]["clean"]
+        assert r[0]["received"] == r[1]["received"] and all(0 < c <= 2 * 600 for c in r[0]["received"])
     # single-process reference: autograd path, loss = mean over the two views
     gut = importlib.import_module("3dgrut_amd"); train = importlib.import_module("3dgrut_amd.train")
     model_mod = importlib.import_module("3dgrut_amd.model"); losses = importlib.import_module("3dgrut_amd.losses")

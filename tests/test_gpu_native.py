@@ -238,6 +238,90 @@ def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
     assert kt["optimizer_early"] > 0 and kt["optimizer"] > 0 and ref.raster.kernel_times()["optimizer_early"] < 0
 
 
+def test_sparse_gradient_records_equal_the_dense_epilogue():
+    """gut_compact_gradient_rows -> gut_scatter_gradient_records rebuilds exactly the [N,12] raw-parameter gradient and the
+    masked dL/dRGB that the dense compact epilogue (GUT_BWD_COMPACT_RADIANCE_GRADS) writes; ids are unique, rows without a
+    gradient get no record, and the handle's gradient rows are left consumed."""
+    sc = scenes.scene_c1(5000, 9)
+    W, H = 96, 80
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, 0.1, -3.0), (0, 0, 0)), fx=90.0)
+    model = native.NativeGaussianModel(sc, device=DEV)
+    st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, fuse_epilogue=False)
+    b = to_batch(view, DEV)
+    rgba, dist_, hits, vis = st.forward(b)
+    g = torch.Generator().manual_seed(3)
+    rgba_grad = torch.randn(rgba.shape, generator=g).to(DEV)
+    _, sensor, poses, _, _ = st._ctx
+    m = st.model
+    args = (st.step_id, m.n_active_features, st.act, m.features, b.rays_ori.contiguous(), b.rays_dir.contiguous(), None, sensor,
+            poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_grad,
+            dist_, None)
+    n = m.num_gaussians
+    g12 = torch.empty((n, 12), device=DEV); mrgb = torch.empty((n, 3), device=DEV)
+    st.raster.trace_bwd(*args, raw_parameter_grads=True, compact_radiance_grads=True, out=(g12, mrgb))
+    st.raster.trace_bwd(*args, skip_epilogue=True)
+    rec = torch.full((n, 16), float("nan"), device=DEV); cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st.raster.compact_gradient_rows(st.act, rec, cnt)
+    c = int(cnt.item())
+    ids = rec[:c, 11].contiguous().view(torch.int32).long()
+    assert 0 < c < n and ids.unique().numel() == c and int(ids.max()) < n
+    has_grad = (g12.abs().sum(1) + mrgb.abs().sum(1)) > 0
+    assert set(ids.tolist()) >= set(torch.nonzero(has_grad).reshape(-1).tolist())   # (a record may carry an all-zero chained row)
+    # the consumed rows are zero again: a second backward + compaction finds the same gradients, not twice their sum
+    st.raster.trace_bwd(*args, skip_epilogue=True)
+    rec2 = torch.empty((n, 16), device=DEV); cnt2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st.raster.compact_gradient_rows(st.act, rec2, cnt2)
+    assert int(cnt2.item()) == c
+    o1, o2 = torch.argsort(ids), torch.argsort(rec2[:c, 11].contiguous().view(torch.int32).long())
+    close = lambda a, b: rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5   # two backward runs differ by float-atomic noise
+    assert close(rec[:c][o1][:, :11], rec2[:c][o2][:, :11]) and close(rec[:c][o1][:, 12:], rec2[:c][o2][:, 12:])
+    acc = torch.zeros((n, 12), device=DEV); slab = torch.zeros((n, 3), device=DEV)
+    lib = st._lib
+    s_ = torch.cuda.current_stream().cuda_stream
+    assert lib.gut_scatter_gradient_records(C.c_void_p(s_), rec.data_ptr(), c, n, acc.data_ptr(), slab.data_ptr()) == 0
+    assert close(acc, g12) and close(slab, mrgb)   # the chain arithmetic is the same
+    assert bool((rec[:c, 15] == 0).all())
+    # a second scatter of the same view accumulates (that is how several views sum up) ...
+    assert lib.gut_scatter_gradient_records(C.c_void_p(s_), rec.data_ptr(), c, n, acc.data_ptr(), slab.data_ptr()) == 0
+    assert close(acc, 2 * g12) and close(slab, mrgb)
+    # ... and a record whose id is not a row of the model is dropped, not stored through
+    bad = rec[:1].clone(); bad[0, 11] = torch.tensor([n + 5], dtype=torch.int32).view(torch.float32)[0]
+    before = acc.clone()
+    assert lib.gut_scatter_gradient_records(C.c_void_p(s_), bad.data_ptr(), 1, n, acc.data_ptr(), slab.data_ptr()) == 0
+    assert torch.equal(acc, before)
+    with pytest.raises(RuntimeError, match="no backward context"):
+        st.raster.compact_gradient_rows(st.act, rec, cnt)
+
+
+def test_sparse_exchange_step_equals_the_one_pass_step():
+    """dp_exchange="sparse" with one rank (records -> scatter -> k_sh_adam<false> with self-clearing accumulators) leaves the
+    parameters of the fused one-pass step over several views, and the dense accumulators all-zero after every step."""
+    sc = scenes.scene_c1(8000, 13)
+    W, H = 128, 96
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(4)).to(DEV)
+    dirs = [(1, 0, 0), (-1, 0.2, 0), (0, 1, 0.1)]
+    views = [make_view("pinhole", W, H, cams.look_at_c2w((0.05 * k, 0.0, 0.02 * k), d), fx=110.0) for k, d in enumerate(dirs)]
+    steppers = []
+    for kw in (dict(), dict(fuse_epilogue=False, dp_exchange="sparse"), dict(fuse_epilogue=False, dp_exchange="dense")):
+        model = native.NativeGaussianModel(sc, device=DEV)
+        steppers.append(native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, overlap_optimizer=False, **kw))
+    hooked = []
+    steppers[1].post_backward_hook = lambda pg, cam: hooked.append(pg.clone())
+    dense_hook = []
+    steppers[2].post_backward_hook = lambda pg, cam: dense_hook.append(pg.clone())
+    for view in views:
+        for st in steppers:
+            b = to_batch(view, DEV); b.rgb_gt = gt
+            st.step(b)
+        sp = steppers[1]
+        assert not bool(sp.g12.any()) and not bool(sp.mrgb[0].any()) and 0 < sp.exchanged_records < 8000
+        assert rel_l2(hooked[-1].cpu().numpy(), dense_hook[-1].cpu().numpy()) <= 1e-5
+    one, sp, de = steppers
+    for a, b_ in ((one.model.raw, sp.model.raw), (one.model.features, sp.model.features), (one.m48, sp.m48), (one.v12, sp.v12),
+                  (de.model.raw, sp.model.raw), (de.model.features, sp.model.features)):
+        assert rel_l2(a.cpu().numpy(), b_.cpu().numpy()) <= 2e-5
+
+
 def test_half_applied_optimiser_step_is_an_error():
     sc, (_, ovl) = _native_pair(n=500)
     view = make_view("pinhole", 64, 48, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64.0)
