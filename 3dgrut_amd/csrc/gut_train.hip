@@ -311,9 +311,13 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
 // of LDS), every workgroup striding over the 256-row blocks.  It is queued in front of the compositing kernel, so its
 // workgroups take their wave slot per SIMD first and keep it until the pass is done; the compositing and loss kernels get
 // everything else and are never queued behind a wall of streaming workgroups (a one-block-per-256-rows grid on a low-priority
-// stream starved the image-sized loss kernels: measured 0.14 -> 0.8 ms).  One wave per SIMD with twelve 16-byte loads in
-// flight (the [N,48] sweep is unrolled four times) keeps a CU's share of the HBM stream busy; two waves per SIMD at half the
-// registers moved the same bytes but spilled to scratch at the 64-VGPR bound (this form has no scratch).
+// stream starved the image-sized loss kernels: measured 0.14 -> 0.8 ms).  One wave per SIMD: the raw row's nine 16-byte loads
+// are issued together, the [N,48] sweep issues three per (p, m, v) group and the next group's loads behind the previous
+// group's stores.  Issuing all twelve loads of four groups before the first use was measured (105 VGPRs): no faster, and one
+// more register block taken from the compositor next door; two waves per SIMD at half the registers moved the same bytes but
+// spilled to scratch at the 64-VGPR bound (this form has no scratch).  Skipping the stores of groups whose moments are all
+// zero (fixed points of the update) made the start of a training run 4 % faster and its steady state 8 % slower (the test
+// sits between the loads and their use): not kept.
 __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamParams a12, AdamParams a48, uint32_t n,
                                                                           const uint32_t* __restrict__ tiles_count,
                                                                           float4* __restrict__ p12, float4* __restrict__ m12,
@@ -337,34 +341,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         const unsigned long long mask = __ballot(mine);
         if (mask == 0ull) continue;  // wave-uniform
         if (mine) {
-            bool continue_row = false;
             // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
             // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
-            // A (p, m, v) group whose moments are all exactly zero — a Gaussian that never received a gradient — is a fixed point
-            // of the zero-gradient update (m' = v' = 0, p' = p - lr * 0 * rcp(eps) = p, bit for bit): nothing is written for it.
             float4 a = p12[3 * (size_t)i + 0], m = m12[3 * (size_t)i + 0], v = v12[3 * (size_t)i + 0];
-            bool moved = false;
-            if (!all_zero(m, v)) {
-                adam4(a12, 0, zero, a, m, v);
-                p12[3 * (size_t)i + 0] = a; m12[3 * (size_t)i + 0] = m; v12[3 * (size_t)i + 0] = v;
-                moved = true;
-            }
+            adam4(a12, 0, zero, a, m, v);
+            p12[3 * (size_t)i + 0] = a; m12[3 * (size_t)i + 0] = m; v12[3 * (size_t)i + 0] = v;
             float4 b = p12[3 * (size_t)i + 1];
             m = m12[3 * (size_t)i + 1]; v = v12[3 * (size_t)i + 1];
-            if (!all_zero(m, v)) {
-                adam4(a12, 4, zero, b, m, v);
-                p12[3 * (size_t)i + 1] = b; m12[3 * (size_t)i + 1] = m; v12[3 * (size_t)i + 1] = v;
-                moved = true;
-            }
+            adam4(a12, 4, zero, b, m, v);
+            p12[3 * (size_t)i + 1] = b; m12[3 * (size_t)i + 1] = m; v12[3 * (size_t)i + 1] = v;
             float4 c = p12[3 * (size_t)i + 2];
             m = m12[3 * (size_t)i + 2]; v = v12[3 * (size_t)i + 2];
-            if (!all_zero(m, v)) {
-                adam4(a12, 8, zero, c, m, v);
-                p12[3 * (size_t)i + 2] = c; m12[3 * (size_t)i + 2] = m; v12[3 * (size_t)i + 2] = v;
-                moved = true;
-            }
-            if (!moved) continue_row = true;   // the activation row is already that of the unchanged raw row
-            if (act12 && !continue_row) activate_row(a, b, c, act12 + 3 * (size_t)i);
+            adam4(a12, 8, zero, c, m, v);
+            p12[3 * (size_t)i + 2] = c; m12[3 * (size_t)i + 2] = m; v12[3 * (size_t)i + 2] = v;
+            if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
         }
         float4* bp = p48 + (size_t)wave_first * 12;
         float4* bm = m48 + (size_t)wave_first * 12;
@@ -376,7 +366,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
             const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
             if (!((mask >> row) & 1ull)) continue;
             float4 pp = bp[q], mm = bm[q], vv = bv[q];
-            if (all_zero(mm, vv)) continue;  // fixed point of the update (see above): no store
             adam4_zero_grad(a48, s_lr48[col >> 2], pp, mm, vv);
             bp[q] = pp; bm[q] = mm; bv[q] = vv;
         }

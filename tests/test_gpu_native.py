@@ -225,7 +225,7 @@ def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
             coasting = early & ever_tiles
             assert int(coasting.sum()) > 0
             assert float((state(ovl)["raw"][coasting] - before[coasting]).abs().max()) > 0
-            # rows that never had a gradient are a fixed point of the update; the side-stream kernel writes nothing for them
+            # rows that never had a gradient are a fixed point of the zero-gradient update
             dormant = early & ~ever_tiles
             if k < 3:
                 assert int(dormant.sum()) > 0
