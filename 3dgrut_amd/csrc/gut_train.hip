@@ -189,13 +189,14 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
     float* wl = tile + wave * 64 * kRow;
     const uint32_t wave_first = blockIdx.x * kBlock + wave * 64u;
     const uint32_t rows_here = wave_first < sp.n ? min(64u, sp.n - wave_first) : 0u;
+    // two-pass optimiser: waves without a single tile were updated whole by k_adam_rows_without_gradient
+    if (kScratch && sp.rows_with_tiles_only && __ballot(i < sp.n && tiles_count[i] != 0) == 0ull) return;
     float G[48];
 #pragma unroll
     for (int k = 0; k < 48; ++k) G[k] = 0.0f;
     bool active = false;
     if (i < sp.n) {
         active = !(visibility && !(visibility[i] != 0.0f));
-        if (kScratch && sp.rows_with_tiles_only && tiles_count[i] == 0) active = false;
         if (active) {
             // --- raw [N,12] row ---
             float4 a = p12[3 * (size_t)i + 0];
@@ -300,8 +301,10 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
     }
 }
 
-// k_adam_rows_without_gradient: the rows k_sh_adam<true> would update with an all-zero gradient — Gaussians the projection
-// gave no tile (tiles_count == 0: culled, off-screen, transparent) — need nothing from the backward pass.  Their Adam step
+// k_adam_rows_without_gradient: rows k_sh_adam<true> would update with an all-zero gradient — Gaussians the projection
+// gave no tile (tiles_count == 0: culled, off-screen, transparent) — need nothing from the backward pass.  This pass takes
+// them by WHOLE WAVES of 64 rows (those in which no row has a tile); rows without tiles inside other waves stay with
+// k_sh_adam<true>, which sees their zero gradient.  Their Adam step
 // (moments decay, parameters keep moving on their momentum, exactly as torch.optim.Adam does with a zero gradient) is
 // pure HBM streaming, so it runs on a low-priority side stream UNDER the VALU-bound compositing kernels of the same
 // iteration; k_sh_adam<true> then only walks the rows that have tiles.  Same adam4 arithmetic, same activation: the
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
                                                                           uint32_t block_end) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_s_setprio(1);  // its few instructions issue ahead of the VALU-saturated compositor next door (+1 % step rate)
     // the [N,48] sweep picks its four learning rates by a per-lane column: keep them in LDS (a register-indexed kernel
     // argument array would live in scratch, and this kernel must not use any: it runs beside other kernels on another queue)
     __shared__ float4 s_lr48[12];
@@ -337,9 +341,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         const uint32_t i = blk * kBlock + threadIdx.x;
         const uint32_t wave_first = blk * kBlock + wave * 64u;
         const uint32_t rows_here = wave_first < n ? min(64u, n - wave_first) : 0u;
-        const bool mine = i < n && tiles_count[i] == 0;
-        const unsigned long long mask = __ballot(mine);
-        if (mask == 0ull) continue;  // wave-uniform
+        // whole waves only: a wave of 64 rows belongs to this pass iff NONE of its rows has a tile (k_sh_adam<true> applies the
+        // same test and takes every other wave whole).  Inside the view frustum about one row in ten has no tile of its own
+        // (sub-pixel or transparent), sprinkled between rows that have: row-granular, this pass visited 55 k such waves for
+        // 13 % of its bytes with mostly-masked loads, and both passes touched those waves' cache lines.
+        const bool mine = i < n;
+        if (__ballot(i < n && tiles_count[i] != 0) != 0ull) continue;
         if (mine) {
             // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
             // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
@@ -364,7 +371,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
             const uint32_t q = (uint32_t)it * 64u + lane;
             if (q >= rows_here * 12u) continue;
             const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
-            if (!((mask >> row) & 1ull)) continue;
             float4 pp = bp[q], mm = bm[q], vv = bv[q];
             adam4_zero_grad(a48, s_lr48[col >> 2], pp, mm, vv);
             bp[q] = pp; bm[q] = mm; bv[q] = vv;

@@ -68,10 +68,12 @@ def algorithmic_bytes(st, kernel, end_bit):
         # Gaussian; 64-byte gradient row read, 12-byte RGB, and the 64-byte row zeroed again (replaces the per-step clear of the
         # whole gradient buffer) per Gaussian with tiles
         "optimizer": 1492 * N + (76 + 64) * V,
-        # split form (default at one view): the rows without tiles (N - V) are updated by k_adam_rows_without_gradient on a side
-        # stream under the compositing kernels, k_sh_adam then walks the V rows with tiles; both read every tile count (4 N)
-        "optimizer_late": 4 * N + (1488 + 76 + 64) * V,
-        "optimizer_early": 4 * N + 1488 * (N - V),
+        # split form (default at one view): the R rows in 64-row waves WITHOUT any tile (st["rows_in_waves_without_tiles"],
+        # counted from the tile counts of the last step) are updated by k_adam_rows_without_gradient on a side stream under the
+        # compositing kernels, k_sh_adam then walks the other N - R rows (V of them have a gradient row); both read every tile
+        # count (4 N)
+        "optimizer_late": 4 * N + 1488 * (N - st.get("rows_in_waves_without_tiles", N - V)) + (76 + 64) * V,
+        "optimizer_early": 4 * N + 1488 * st.get("rows_in_waves_without_tiles", N - V),
     }[kernel]
 
 
@@ -312,6 +314,12 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     ktimes, kcount = raster.kernel_times_mean()
     fb = raster.collect_times()
     stats = raster.stats()
+    cnt = raster.debug_buffer("tiles_count")
+    if cnt.numel():
+        pad = (-cnt.numel()) % 64
+        waves = torch.nn.functional.pad(cnt, (0, pad)).view(-1, 64)
+        empty = ~(waves != 0).any(1)
+        stats["rows_in_waves_without_tiles"] = int(empty.sum().item()) * 64 - (pad if bool(empty[-1]) else 0)
 
     # forward-only render time (reference's FPS definition: mean forward_render ms, threedgrut/render.py:231-251)
     with torch.no_grad():
