@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/profiles
 rm -rf "$OUT"; mkdir -p "$OUT"   # NB: also delete gpurun_out/profiles locally before the call (gpurun merges, it does not mirror)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --steps 20 --warmup 5 \
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-sensitivity \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err" || exit 1
 echo "stats pass done"
 timeout -k 10 300 python3 "$R/bench.py" --steps 20 --warmup 5 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err" || exit 1

@@ -129,7 +129,7 @@ plain = json.load(open(os.path.join(dst, "bench_plain.json")))
 prof = json.load(open(os.path.join(dst, "bench_under_rocprof.json")))
 L = ["# Profiles (" + rnd + ")\n",
      "Collected with `tools/collect_profiles.sh` on one MI355X (gpurun), post-processed by `tools/profile_report.py`.\n",
-     "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5`\n",
+     "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-sensitivity` (the plain run next to it: `python3 bench.py --steps 20 --warmup 5`)\n",
      "Files: `bench_kernel_stats.csv` (rocprofv3 per-kernel summary of that run), `bench_under_rocprof.json` (the bench line printed "
      "under the profiler), `bench_plain.json` (same command without the profiler, same box), `pmc_traffic.json` (HBM bytes per launch "
      "from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes), `pmc_sq.json` (SQ / TCC / GRBM counters per launch from three more "
@@ -152,7 +152,7 @@ for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimize
              f"{g(e, 'SQ_INSTS_VALU', '{:.3e}')} | {g(e, 'valu_issue_frac', '{:.2f}')} | {g(e, 'valu_active_frac', '{:.2f}')} | "
              f"{g(e, 'SQ_INSTS_LDS', '{:.3e}')} | {g(e, 'SQ_LDS_BANK_CONFLICT', '{:.3e}')} | {g(e, 'atomic_GBps', '{:.0f}')} |")
 L += ["", "`optimizer_early` is launched twice per step (25 % / 75 % of the row blocks): its row is the mean of the two launches, "
-          "double it for the per-step total.  In this steady state it writes nothing for rows whose moments are still exactly zero.",
+          "double it for the per-step total.",
       "", "Top kernels (all launches of the run: 25 train steps + 10 render-only frames + setup):\n",
       "| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|"]
 for r in rows[:18]:
@@ -160,7 +160,18 @@ for r in rows[:18]:
 L.append("")
 dom = [r for r in rows if key_of(r["Name"]) == plain["roofline"]["kernel"]]
 if dom:
-    L.append(f"rocprofv3's average for the dominant kernel (`{dom[0]['Name'][:40]}`: {float(dom[0]['AverageNs']) / 1e3:.1f} us) and the live "
-             f"hipEvent mean in the bench line (`roofline.mean_launch_ms` = {prof['roofline']['mean_launch_ms']:.3f} ms under the profiler, "
-             f"{plain['roofline']['mean_launch_ms']:.3f} ms plain).\n")
+    # the same kernel's dispatches inside the bench's TIMED region: the last `steps` dispatches in the kernel trace of the stats
+    # run (the run-wide average above also holds the warm-up, whose steps 1-4 alternate the one- and two-pass optimiser)
+    tr = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
+    timed = None
+    if tr:
+        d = [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3 for r in csv.DictReader(open(tr[0]))
+             if key_of(r["Kernel_Name"]) == plain["roofline"]["kernel"]]
+        w0, k0 = int(prof["warmup"]), int(prof["steps"])
+        d = d[w0:w0 + k0]   # the headline workload comes first in the run
+        timed = sum(d) / len(d) if d else None
+    L.append(f"rocprofv3's average for the dominant kernel (`{dom[0]['Name'][:40]}`) over the whole run: {float(dom[0]['AverageNs']) / 1e3:.1f} us"
+             + (f"; over dispatches {int(prof['warmup'])}..{int(prof['warmup']) + int(prof['steps']) - 1} (the bench's timed region): **{timed:.1f} us**" if timed else "")
+             + f".  Live hipEvent mean in the bench line of the same run (`roofline.mean_launch_ms`): {prof['roofline']['mean_launch_ms'] * 1e3:.1f} us "
+             f"(plain run: {plain['roofline']['mean_launch_ms'] * 1e3:.1f} us).\n")
 open(os.path.join(dst, "README.md"), "w").write("\n".join(L))

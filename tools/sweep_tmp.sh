@@ -1,9 +1,9 @@
 set -o pipefail
 mkdir -p gpurun_out
-for i in 1 2 3; do
-for v in g0 g1; do
-  GUT_HIP_LIB=$PWD/3dgrut_amd/libgut_hip_$v.so python bench.py --steps 40 --warmup 12 --no-sensitivity --no-cpu-baseline > gpurun_out/wg_${v}_$i.json 2> gpurun_out/wg_${v}_$i.err || exit 1
+python -m pytest tests -x -q -m gpu > gpurun_out/r2_full.log 2>&1; echo rc=$? >> gpurun_out/r2_full.log; tail -3 gpurun_out/r2_full.log
+grep -q "rc=0" gpurun_out/r2_full.log || exit 1
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2_smoke.log 2>&1; echo rc=$? >> gpurun_out/r2_smoke.log; tail -2 gpurun_out/r2_smoke.log
+for w in c1_1k_128x128 lego_like_300k_800x800 scannetpp_like_fisheye_300k_1752x1168 garden_like_5M_1297x840; do
+  python bench.py --workload $w --steps 40 --warmup 12 > gpurun_out/wl_$w.json 2> gpurun_out/wl_$w.err || exit 1
 done
-done
-GUT_HIP_LIB=$PWD/3dgrut_amd/libgut_hip_g1.so python -m pytest tests/test_gpu_native.py tests/test_gpu_fullsize.py -x -q -m gpu > gpurun_out/r2_t20.log 2>&1; echo rc=$? >> gpurun_out/r2_t20.log; tail -3 gpurun_out/r2_t20.log
-echo done
+bash tools/collect_profiles.sh
