@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  # override: dev experiments only
 
 GUT_ABI_VERSION = 1
-GUT_NUM_KERNEL_TIMERS = 10
+GUT_NUM_KERNEL_TIMERS = 11
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
 BWD_SKIP_EPILOGUE = 4
@@ -19,8 +19,9 @@ OPT_LAZY_TILE_ORDER = 1
 ADAM_CLEAR_CONSUMED_GRADS = 1
 GRADIENT_RECORD_FLOATS = 16
 OPT_SORTED_REFERENCE_BACKWARD = 2
+OPT_EARLY_EXTRA_PERCENT = 3
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer",
-                      "optimizer_early")
+                      "optimizer_early", "optimizer_early_2")
 
 SHUTTER_GLOBAL = 4
 CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
@@ -58,6 +59,7 @@ class GutStats(C.Structure):
         ("num_particles", C.c_uint64), ("num_visible", C.c_uint64), ("num_intersections", C.c_uint64),
         ("num_tiles", C.c_uint64), ("num_pixels", C.c_uint64), ("traversed_fwd", C.c_uint64),
         ("traversed_bwd", C.c_uint64), ("sort_end_bit", C.c_uint32), ("binning_overflows", C.c_uint32),
+        ("side_stream_rows", C.c_uint64), ("side_stream_rows_first_launch", C.c_uint64),
     ]
 
 

@@ -160,7 +160,12 @@ struct gut_context {
         float lr12[12], lr48[48];
         float beta1, beta2, eps;
         uint32_t step, block_begin, block_end;
+        uint32_t extra_end;   // blocks < extra_end: waves with tiles the forward did not walk also go to the second launch
     } early_args{};
+    DevBuf wave_walked;       // one byte per 64-row wave (k_mark_walked_waves), valid when early_args.extra_end > 0
+    int early_extra_percent = 100;
+    bool stats_early = false;   // the last optimiser step used the side stream (for gut_get_stats)
+    uint32_t stats_split = 0, stats_extra_end = 0;
     bool early_part2_pending = false;
     hipEvent_t ev_bwd_start = nullptr;
     bool early_ran = false;           // the cached forward's rows without tiles already had their optimiser step
@@ -189,7 +194,7 @@ struct gut_context {
     static constexpr int kRing = 64;
     struct KevSet {
         hipEvent_t e[16] = {};
-        bool fwd = false, bwd = false, opt = false, early = false;
+        bool fwd = false, bwd = false, opt = false, early = false, early2 = false;
     };
     KevSet ring[kRing];
     int ring_cur = 0;    // set used by the most recent trace()
@@ -376,7 +381,7 @@ void gut_destroy(gut_handle h) {
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
                       &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters, &h->ids_ordered,
-                      &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered};
+                      &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered, &h->wave_walked};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
@@ -452,6 +457,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
         h->ring[h->ring_cur].bwd = false;
         h->ring[h->ring_cur].opt = false;
         h->ring[h->ring_cur].early = false;
+        h->ring[h->ring_cur].early2 = false;
     }
     auto mark = [&](int i) {
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
@@ -686,8 +692,7 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
                                h->ranges.as<uint32_t>(), (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(),
                                d_ray_radiance_density,
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
-                               h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>(),
-                               h->lazy_order ? h->tile_ordered.as<uint32_t>() : nullptr);
+                               h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>(), h->trav_fwd.as<uint32_t>());
     }
     mark(10);
     if (flags & GUT_BWD_SKIP_EPILOGUE) {
@@ -736,7 +741,9 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     if (timing) (void)hipEventRecord(h->kev[12], s);
     gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, d_camera_position, h->grad16.as<float>(), h->tiles_count.as<uint32_t>(),
                                      h->feat.as<float>(), d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12, lr48, beta1, beta2,
-                                     eps, step, d_visibility, d_act12_out, h->early_ran);
+                                     eps, step, d_visibility, d_act12_out, h->early_ran,
+                                     (h->early_ran && h->early_args.extra_end) ? h->wave_walked.as<uint8_t>() : nullptr,
+                                     h->early_args.block_begin, h->early_ran ? h->early_args.extra_end : 0u);
     HIP_TRY(hipGetLastError());
     if (timing) {
         (void)hipEventRecord(h->kev[13], s);
@@ -746,6 +753,9 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
         HIP_TRY(hipStreamWaitEvent(s, h->ev_early_done, 0));
         h->early_wait_pending = false;
     }
+    h->stats_early = h->early_ran;
+    h->stats_split = h->early_args.block_begin;
+    h->stats_extra_end = h->early_ran ? h->early_args.extra_end : 0u;
     h->early_ran = false;
     h->have_backward = false;  // the gradient rows are consumed ...
     h->grad16_zero = true;     // ... and left zero by the kernel
@@ -813,7 +823,8 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     const uint32_t nblocks = (h->n + gut::kBlock - 1) / gut::kBlock;
     const uint32_t first = (uint32_t)((uint64_t)nblocks * (uint32_t)split_percent / 100u);
     gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), d_raw12, d_raw_m, d_raw_v, d_sh48,
-                                           d_sh_m, d_sh_v, lr12, lr48, beta1, beta2, eps, step, d_act12_out, 0, first);
+                                           d_sh_m, d_sh_v, lr12, lr48, beta1, beta2, eps, step, d_act12_out, 0, first, nullptr, first, 0,
+                                           false);
     HIP_TRY(hipGetLastError());
     gut_context::EarlyArgs& ea = h->early_args;
     ea.raw12 = d_raw12; ea.raw_m = d_raw_m; ea.raw_v = d_raw_v; ea.sh48 = d_sh48; ea.sh_m = d_sh_m; ea.sh_v = d_sh_v;
@@ -821,7 +832,11 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     memcpy(ea.lr12, lr12, sizeof(ea.lr12));
     memcpy(ea.lr48, lr48, sizeof(ea.lr48));
     ea.beta1 = beta1; ea.beta2 = beta2; ea.eps = eps; ea.step = step; ea.block_begin = first; ea.block_end = nblocks;
-    h->early_part2_pending = first < nblocks;
+    // unsorted variant with something to walk: the second launch also takes, in the first early_extra_percent of the blocks,
+    // the waves with tiles in which the forward walked no Gaussian (see launch_early_part2)
+    ea.extra_end = (h->cfg.k_buffer_size == 0 && h->m) ? (uint32_t)((uint64_t)nblocks * (uint32_t)h->early_extra_percent / 100u) : 0u;
+    if (ea.extra_end) HIP_TRY(h->wave_walked.ensure(((size_t)h->n + 63) / 64));
+    h->early_part2_pending = first < nblocks || ea.extra_end > 0;
     if (timing) {
         (void)hipEventRecord(h->kev[15], h->side_stream);  // re-recorded behind the second launch
         h->ring[h->ring_cur].early = true;
@@ -837,15 +852,27 @@ static int launch_early_part2(gut_context* h, hipStream_t s) {
     if (!h->early_part2_pending) return 0;
     h->early_part2_pending = false;
     if (!h->ev_bwd_start) HIP_TRY(hipEventCreateWithFlags(&h->ev_bwd_start, hipEventDisableTiming));
+    const gut_context::EarlyArgs& ea = h->early_args;
+    if (ea.extra_end) {
+        // The forward compositor is done by now: mark the waves that hold a Gaussian it walked.  The backward compositor walks
+        // no further than the forward did (it is bounded by the forward's per-tile depth), so every other wave is gradient-free.
+        HIP_TRY(hipMemsetAsync(h->wave_walked.p, 0, ((size_t)h->n + 63) / 64, s));
+        gut::launch_mark_walked_waves(s, h->n, (uint32_t)h->tiles, h->ranges.as<uint32_t>(), h->trav_fwd.as<uint32_t>(),
+                                      (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(), h->wave_walked.as<uint8_t>());
+    }
     HIP_TRY(hipEventRecord(h->ev_bwd_start, s));
     HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_bwd_start, 0));
-    const gut_context::EarlyArgs& ea = h->early_args;
+    if (h->cfg.enable_kernel_timings != 0 && h->kev[7]) (void)hipEventRecord(h->kev[7], h->side_stream);  // start of the second launch
     gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), ea.raw12, ea.raw_m, ea.raw_v, ea.sh48,
                                            ea.sh_m, ea.sh_v, ea.lr12, ea.lr48, ea.beta1, ea.beta2, ea.eps, ea.step, ea.act12,
-                                           ea.block_begin, ea.block_end);
+                                           ea.extra_end ? 0u : ea.block_begin, ea.block_end,
+                                           ea.extra_end ? h->wave_walked.as<uint8_t>() : nullptr, ea.block_begin, ea.extra_end, true);
     HIP_TRY(hipGetLastError());
     const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[14] && h->kev[15];
-    if (timing) (void)hipEventRecord(h->kev[15], h->side_stream);
+    if (timing) {
+        (void)hipEventRecord(h->kev[15], h->side_stream);
+        h->ring[h->ring_cur].early2 = h->kev[7] != nullptr;
+    }
     HIP_TRY(hipEventRecord(h->ev_early_done, h->side_stream));
     return 0;
 }
@@ -856,6 +883,10 @@ int gut_set_option(gut_handle h, int32_t option, int32_t value) {
     switch (option) {
     case GUT_OPT_LAZY_TILE_ORDER: h->lazy_enabled = value != 0; return 0;
     case GUT_OPT_SORTED_REFERENCE_BACKWARD: h->sorted_reference_bwd = value != 0; return 0;
+    case GUT_OPT_EARLY_EXTRA_PERCENT:
+        if (value < 0 || value > 100) return fail("gut_set_option: GUT_OPT_EARLY_EXTRA_PERCENT takes 0..100");
+        h->early_extra_percent = value;
+        return 0;
     default: return fail("gut_set_option: unknown option %d", option);
     }
 }
@@ -895,7 +926,8 @@ int gut_kernel_times(gut_handle h, float* ms8) {
         ms8[7] = span(10, 11);  // project backward
     }
     if (h->ring[h->ring_cur].opt) ms8[8] = span(12, 13);  // one-pass optimiser (gut_optimize_after_bwd)
-    if (h->ring[h->ring_cur].early) ms8[9] = span(14, 15);  // rows without tiles, on the side stream
+    if (h->ring[h->ring_cur].early) ms8[9] = span(14, 15);  // side-stream pass, start of its first to end of its second launch
+    if (h->ring[h->ring_cur].early2) ms8[10] = span(7, 15);  // its second launch alone
     return 0;
 }
 
@@ -905,12 +937,12 @@ int gut_kernel_times_mean(gut_handle h, float* ms8, int32_t* count) {
     if (!h->cfg.enable_kernel_timings) return fail("gut_kernel_times_mean: enable_kernel_timings is off");
     double sum[GUT_NUM_KERNEL_TIMERS] = {};
     int cnt[GUT_NUM_KERNEL_TIMERS] = {};
-    static const int kA[GUT_NUM_KERNEL_TIMERS] = {0, 1, 2, 3, 4, 5, 9, 10, 12, 14};
-    static const int kB[GUT_NUM_KERNEL_TIMERS] = {1, 2, 3, 4, 5, 6, 10, 11, 13, 15};
+    static const int kA[GUT_NUM_KERNEL_TIMERS] = {0, 1, 2, 3, 4, 5, 9, 10, 12, 14, 7};
+    static const int kB[GUT_NUM_KERNEL_TIMERS] = {1, 2, 3, 4, 5, 6, 10, 11, 13, 15, 15};
     for (int k = 0; k < h->ring_count; ++k) {
         const auto& set = h->ring[(h->ring_cur - k + 2 * gut_context::kRing) % gut_context::kRing];
         for (int i = 0; i < GUT_NUM_KERNEL_TIMERS; ++i) {
-            const bool ok = i < 6 ? set.fwd : (i < 8 ? set.bwd : (i == 8 ? set.opt : set.early));
+            const bool ok = i < 6 ? set.fwd : (i < 8 ? set.bwd : (i == 8 ? set.opt : (i == 9 ? set.early : set.early2)));
             if (!ok || !set.e[kA[i]] || !set.e[kB[i]]) continue;
             float ms = 0.f;
             if (hipEventSynchronize(set.e[kB[i]]) == hipSuccess && hipEventElapsedTime(&ms, set.e[kA[i]], set.e[kB[i]]) == hipSuccess) {
@@ -935,6 +967,10 @@ int gut_get_stats(gut_handle h, GutStats* out) {
     HIP_TRY(hipMemsetAsync(h->counters.p, 0, sizeof(gut::Counters), h->fwd_stream));
     gut::launch_stats_reduce(h->fwd_stream, h->n, h->tiles_count.as<uint32_t>(), (uint32_t)h->tiles, h->trav_fwd.as<uint32_t>(),
                              h->trav_bwd.as<uint32_t>(), h->counters.as<gut::Counters>());
+    if (h->stats_early)
+        gut::launch_count_side_stream_rows(h->fwd_stream, h->n, h->tiles_count.as<uint32_t>(),
+                                           h->stats_extra_end ? h->wave_walked.as<uint8_t>() : nullptr, h->stats_split,
+                                           h->stats_extra_end, h->counters.as<gut::Counters>());
     gut::Counters c;
     HIP_TRY(hipMemcpyAsync(&c, h->counters.p, sizeof(c), hipMemcpyDeviceToHost, h->fwd_stream));
     HIP_TRY(hipStreamSynchronize(h->fwd_stream));
@@ -947,6 +983,8 @@ int gut_get_stats(gut_handle h, GutStats* out) {
     out->traversed_bwd = c.traversed_bwd;
     out->sort_end_bit = (uint32_t)h->end_bit;
     out->binning_overflows = (uint32_t)h->overflows;
+    out->side_stream_rows = c.side_stream_rows;
+    out->side_stream_rows_first_launch = c.side_stream_rows_first;
     return 0;
 }
 

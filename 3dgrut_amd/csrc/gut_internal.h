@@ -50,7 +50,9 @@ struct Counters {
     unsigned long long visible;        // V
     unsigned long long traversed_fwd;  // E_f
     unsigned long long traversed_bwd;  // E_b
-    unsigned long long pad[5];
+    unsigned long long side_stream_rows;
+    unsigned long long side_stream_rows_first;
+    unsigned long long pad[3];
 };
 
 // ---- launch wrappers implemented in the .hip files -------------------------------------------------
@@ -78,7 +80,7 @@ void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
                        float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order,
-                       const uint32_t* tile_ordered /* lazy order: valid prefix of each tile's list, else NULL */);
+                       const uint32_t* tile_walked /* forward's per-tile traversal depth: the backward stops there */);
 void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order);
 // sorted (k_buffer_size > 0) compositor variant, gut_render_sorted.hip
 void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
@@ -94,14 +96,20 @@ void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density1
 void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const float* d_camera_position, float* grad16,
                                  const uint32_t* tiles_count, const float* feat, float* raw12, float* raw_m, float* raw_v,
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
-                                 float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only);
+                                 float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only,
+                                 const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end);
 // Adam step of the rows that get no gradient this iteration (tiles_count == 0), see k_adam_rows_without_gradient
 void launch_compact_gradient_rows(hipStream_t s, uint32_t n, const float* act12, const uint32_t* tiles_count, const float* feat,
                                   float* grad16, float* records, uint32_t capacity, uint32_t* count);
 void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t* tiles_count, float* raw12, float* raw_m, float* raw_v,
                                        float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* act12_out,
-                                       uint32_t block_begin, uint32_t block_end /* range of 256-row blocks */);
+                                       uint32_t block_begin, uint32_t block_end /* range of 256-row blocks */,
+                                       const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end, bool second_launch);
+void launch_count_side_stream_rows(hipStream_t s, uint32_t n, const uint32_t* tiles_count, const uint8_t* wave_walked,
+                                   uint32_t split_block, uint32_t extra_end, Counters* out);
+void launch_mark_walked_waves(hipStream_t s, uint32_t n, uint32_t tiles, const uint32_t* ranges, const uint32_t* tile_walked,
+                              const uint32_t* ids, uint8_t* wave_walked);
 void launch_stats_reduce(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint32_t t, const uint32_t* trav_fwd,
                          const uint32_t* trav_bwd, Counters* out);
 

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
                                                            const float* __restrict__ dist_grad, float* __restrict__ grad16,
                                                            uint32_t* __restrict__ tile_traversed,
                                                            const uint32_t* __restrict__ tile_order,
-                                                           const uint32_t* __restrict__ tile_ordered) {
+                                                           const uint32_t* __restrict__ tile_walked) {
     constexpr int W = AccLayout<kDistGrad>::kW;
     __shared__ FwdEntry stage[kBlock];
     __shared__ float acc[kBlock * W];
@@ -430,9 +430,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, Ren
     const float rex = usable ? ray.ex : 0.0f, rey = usable ? ray.ey : 0.0f, rez = usable ? ray.ez : 0.0f;
 
     uint2 range = ranges[tile];
-    // lazy order: sorted_ids is the forward's ordered-id list, valid for the prefix of the tile's list the forward staged;
-    // behind it the list ends, exactly as at a padding id
-    if (tile_ordered) range.y = range.x + min(range.y - range.x, tile_ordered[tile]);
+    // The backward walks no further than the forward did: tile_walked[tile] is the deepest list position any pixel of the tile
+    // consumed in k_render (its whole-tile termination point).  With the lazy order that is also what makes sorted_ids — the
+    // forward's ordered-id list — valid: only the prefix the forward staged is ordered.  The rays terminate by the same rule in
+    // both kernels, so the bound only bites where the two evaluations of a transmittance disagree in the last bit; what it buys
+    // is a guarantee: a Gaussian outside the walked prefixes receives no gradient (the side-stream optimiser pass relies on it).
+    range.y = range.x + min(range.y - range.x, tile_walked[tile]);
     const uint32_t total = range.y - range.x;
     const uint32_t my_slot = reduce_slot(lane);
     bool alive = ray.valid && usable;
@@ -744,14 +747,14 @@ void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed,
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order, const uint32_t* tile_ordered) {
+                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order, const uint32_t* tile_walked) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     auto kern = dist_grad != nullptr ? k_render_backward<true> : k_render_backward<false>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
                        reinterpret_cast<const float4*>(rgba), reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
-                       tile_traversed, tile_order, tile_ordered);
+                       tile_traversed, tile_order, tile_walked);
 }
 
 }  // namespace gut

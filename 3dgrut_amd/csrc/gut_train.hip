@@ -94,6 +94,29 @@ __global__ __launch_bounds__(kBlock) void k_mcmc_relocation(int n, const float* 
 // the wave then streams the contiguous 12 KiB blocks of p / m / v with fully coalesced 16-byte accesses, picking
 // the matching gradients out of LDS.  Traffic per Gaussian: 12 B x views + 48 (grad12) + 6 x 240 (p,m,v in/out).
 // ---------------------------------------------------------------------------------------------------
+// Which 64-row waves the side-stream optimiser pass owns (everything else belongs to k_sh_adam<true>); both kernels call this.
+//   first launch  (walked == nullptr): waves without a tile, in the 256-row blocks [block_begin, block_end)
+//   second launch (walked != nullptr): the waves without a tile of the blocks >= split_block (those below were the first launch's)
+//                                      + in the blocks < extra_end, waves WITH tiles in which the forward walked no Gaussian
+//                                        (walked[w] == 0): the backward walks no further than the forward did, so they cannot
+//                                        receive a gradient either — known only once the forward compositor has finished
+struct EarlyOwnership {
+    const uint8_t* walked;   // per wave, or nullptr
+    uint32_t split_block;    // first block of the second launch's share of the waves without tiles
+    uint32_t extra_end;      // blocks < extra_end: unwalked waves with tiles also go to the second launch
+};
+__device__ __forceinline__ bool side_stream_owns_wave(const EarlyOwnership& o, bool has_tiles, uint32_t wave_index, uint32_t blk,
+                                                      bool second_launch) {
+    if (!has_tiles) return second_launch ? blk >= o.split_block : blk < o.split_block;
+    if (!o.walked || blk >= o.extra_end) return false;
+    return second_launch && o.walked[wave_index] == 0;
+}
+// either launch (what k_sh_adam<true> must leave alone)
+__device__ __forceinline__ bool side_stream_owns_wave(const EarlyOwnership& o, bool has_tiles, uint32_t wave_index, uint32_t blk) {
+    if (!has_tiles) return true;
+    return o.walked && blk < o.extra_end && o.walked[wave_index] == 0;
+}
+
 struct ShAdamParams {
     AdamParams a12, a48;
     const float* cam;  // device [views,3]: sensor positions in world space
@@ -101,7 +124,8 @@ struct ShAdamParams {
     uint32_t view_stride;  // rows between consecutive views in mrgb (>= n)
     int32_t sh_degree;
     float grad_scale;
-    int32_t rows_with_tiles_only;  // kScratch: rows with tiles_count == 0 were already updated by k_adam_rows_without_gradient
+    int32_t rows_with_tiles_only;  // kScratch: the side-stream pass (k_adam_rows_without_gradient) already updated its waves
+    EarlyOwnership own;            // ... which are these
     int32_t clear_consumed;        // !kScratch: gradient rows that were non-zero are written back as zeros (sparse exchange: the
                                    // dense accumulators are only ever touched where a record landed, never cleared wholesale)
 };
@@ -190,7 +214,9 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
     const uint32_t wave_first = blockIdx.x * kBlock + wave * 64u;
     const uint32_t rows_here = wave_first < sp.n ? min(64u, sp.n - wave_first) : 0u;
     // two-pass optimiser: waves without a single tile were updated whole by k_adam_rows_without_gradient
-    if (kScratch && sp.rows_with_tiles_only && __ballot(i < sp.n && tiles_count[i] != 0) == 0ull) return;
+    if (kScratch && sp.rows_with_tiles_only &&
+        side_stream_owns_wave(sp.own, __ballot(i < sp.n && tiles_count[i] != 0) != 0ull, wave_first >> 6, blockIdx.x))
+        return;
     float G[48];
 #pragma unroll
     for (int k = 0; k < 48; ++k) G[k] = 0.0f;
@@ -327,7 +353,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
                                                                           float4* __restrict__ v12, float4* __restrict__ p48,
                                                                           float4* __restrict__ m48, float4* __restrict__ v48,
                                                                           float4* __restrict__ act12, uint32_t block_begin,
-                                                                          uint32_t block_end) {
+                                                                          uint32_t block_end, EarlyOwnership own,
+                                                                          uint32_t second_launch) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_s_setprio(1);  // its few instructions issue ahead of the VALU-saturated compositor next door (+1 % step rate)
@@ -341,12 +368,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         const uint32_t i = blk * kBlock + threadIdx.x;
         const uint32_t wave_first = blk * kBlock + wave * 64u;
         const uint32_t rows_here = wave_first < n ? min(64u, n - wave_first) : 0u;
-        // whole waves only: a wave of 64 rows belongs to this pass iff NONE of its rows has a tile (k_sh_adam<true> applies the
-        // same test and takes every other wave whole).  Inside the view frustum about one row in ten has no tile of its own
+        // whole waves only (side_stream_owns_wave): first of all the waves in which NO row has a tile (k_sh_adam<true> applies
+        // the same test and takes every other wave whole).  Inside the view frustum about one row in ten has no tile of its own
         // (sub-pixel or transparent), sprinkled between rows that have: row-granular, this pass visited 55 k such waves for
         // 13 % of its bytes with mostly-masked loads, and both passes touched those waves' cache lines.
         const bool mine = i < n;
-        if (__ballot(i < n && tiles_count[i] != 0) != 0ull) continue;
+        if (!side_stream_owns_wave(own, __ballot(i < n && tiles_count[i] != 0) != 0ull, wave_first >> 6, blk, second_launch != 0u)) continue;
         if (mine) {
             // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
             // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
@@ -480,10 +507,12 @@ namespace gut {
 void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const float* d_camera_position, float* grad16,
                                  const uint32_t* tiles_count, const float* feat, float* raw12, float* raw_m, float* raw_v,
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
-                                 float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only) {
+                                 float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only,
+                                 const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end) {
     if (n == 0) return;
     ShAdamParams sp;
     sp.rows_with_tiles_only = rows_with_tiles_only ? 1 : 0;
+    sp.own.walked = wave_walked; sp.own.split_block = split_block; sp.own.extra_end = extra_end;
     sp.clear_consumed = 0;
     fill_adam(sp.a12, lr12, 12, beta1, beta2, eps, step);
     fill_adam(sp.a48, lr48, 48, beta1, beta2, eps, step);
@@ -498,8 +527,11 @@ void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const
 void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t* tiles_count, float* raw12, float* raw_m, float* raw_v,
                                        float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* act12_out, uint32_t block_begin,
-                                       uint32_t block_end) {
+                                       uint32_t block_end, const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end,
+                                       bool second_launch) {
     if (n == 0 || block_end <= block_begin) return;
+    EarlyOwnership own;
+    own.walked = wave_walked; own.split_block = split_block; own.extra_end = extra_end;
     AdamParams a12, a48;
     fill_adam(a12, lr12, 12, beta1, beta2, eps, step);
     fill_adam(a48, lr48, 48, beta1, beta2, eps, step);
@@ -520,12 +552,53 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
         wgs_per_cu2 = e2 ? atoi(e2) : wgs_per_cu;
         if (wgs_per_cu2 < 1 || wgs_per_cu2 > 8) wgs_per_cu2 = wgs_per_cu;
     }
-    const uint32_t cap = (uint32_t)(block_begin == 0 ? wgs_per_cu : wgs_per_cu2) * (uint32_t)num_cus;
+    const uint32_t cap = (uint32_t)(second_launch ? wgs_per_cu2 : wgs_per_cu) * (uint32_t)num_cus;
     const uint32_t grid = nblocks < cap ? nblocks : cap;
     hipLaunchKernelGGL(k_adam_rows_without_gradient, dim3(grid), dim3(kBlock), 0, s, a12, a48, n, tiles_count,
                        reinterpret_cast<float4*>(raw12), reinterpret_cast<float4*>(raw_m), reinterpret_cast<float4*>(raw_v),
                        reinterpret_cast<float4*>(sh48), reinterpret_cast<float4*>(sh_m), reinterpret_cast<float4*>(sh_v),
-                       reinterpret_cast<float4*>(act12_out), block_begin, block_end);
+                       reinterpret_cast<float4*>(act12_out), block_begin, block_end, own, second_launch ? 1u : 0u);
+}
+
+// k_mark_walked_waves: wave_walked[id / 64] = 1 for every Gaussian id among the list entries the forward compositor walked
+// (the first tile_walked[tile] entries of each tile's ordered list).  One workgroup per tile; racing stores all write 1.
+__global__ __launch_bounds__(kBlock) void k_mark_walked_waves(uint32_t n, const uint2* __restrict__ ranges,
+                                                             const uint32_t* __restrict__ tile_walked,
+                                                             const uint32_t* __restrict__ ids, uint8_t* __restrict__ wave_walked) {
+    const uint2 r = ranges[blockIdx.x];
+    const uint32_t depth = min(r.y - r.x, tile_walked[blockIdx.x]);
+    for (uint32_t j = threadIdx.x; j < depth; j += kBlock) {
+        const uint32_t id = ids[r.x + j];
+        if (id < n) wave_walked[id >> 6] = 1;
+    }
+}
+
+// statistics (gut_get_stats): rows in the waves the side-stream pass owned in the last step
+__global__ __launch_bounds__(kBlock) void k_count_side_stream_rows(uint32_t n, const uint32_t* __restrict__ tiles_count,
+                                                                  EarlyOwnership own, Counters* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t wave_first = i & ~63u;
+    const bool has_tiles = __ballot(i < n && tiles_count[i] != 0) != 0ull;
+    if (wave_first < n && (threadIdx.x & 63) == 0 && side_stream_owns_wave(own, has_tiles, wave_first >> 6, blockIdx.x)) {
+        atomicAdd(&out->side_stream_rows, (unsigned long long)min(64u, n - wave_first));
+        if (side_stream_owns_wave(own, has_tiles, wave_first >> 6, blockIdx.x, false))
+            atomicAdd(&out->side_stream_rows_first, (unsigned long long)min(64u, n - wave_first));
+    }
+}
+
+void launch_count_side_stream_rows(hipStream_t s, uint32_t n, const uint32_t* tiles_count, const uint8_t* wave_walked,
+                                   uint32_t split_block, uint32_t extra_end, Counters* out) {
+    if (n == 0) return;
+    EarlyOwnership own;
+    own.walked = wave_walked; own.split_block = split_block; own.extra_end = extra_end;
+    hipLaunchKernelGGL(k_count_side_stream_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, tiles_count, own, out);
+}
+
+void launch_mark_walked_waves(hipStream_t s, uint32_t n, uint32_t tiles, const uint32_t* ranges, const uint32_t* tile_walked,
+                              const uint32_t* ids, uint8_t* wave_walked) {
+    if (n == 0 || tiles == 0) return;
+    hipLaunchKernelGGL(k_mark_walked_waves, dim3(tiles), dim3(kBlock), 0, s, n, reinterpret_cast<const uint2*>(ranges), tile_walked,
+                       ids, wave_walked);
 }
 }  // namespace gut
 
@@ -594,6 +667,7 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
     sp.n = num_particles; sp.views = num_views; sp.sh_degree = sh_degree; sp.grad_scale = grad_scale;
     sp.view_stride = mrgb_view_stride ? mrgb_view_stride : num_particles;
     sp.rows_with_tiles_only = 0;
+    sp.own.walked = nullptr; sp.own.split_block = 0; sp.own.extra_end = 0;
     sp.clear_consumed = (flags & GUT_ADAM_CLEAR_CONSUMED_GRADS) ? 1 : 0;
     if (sp.view_stride < num_particles) return 3;
     hipLaunchKernelGGL(gut::k_sh_adam<false>, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,

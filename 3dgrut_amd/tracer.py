@@ -322,6 +322,11 @@ class SplatRaster:
         """Tile-only radix grouping + per-tile lazy depth order in the forward compositor (default on; gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_LAZY_TILE_ORDER, 1 if on else 0), "set_option")
 
+    def set_early_extra_percent(self, percent):
+        """Share of the row blocks in which the second side-stream optimiser launch also takes the waves that have tiles but
+        hold no Gaussian the forward walked (GUT_OPT_EARLY_EXTRA_PERCENT, default 100; 0 = waves without tiles only)."""
+        _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_EARLY_EXTRA_PERCENT, int(percent)), "set_option")
+
     def set_sorted_reference_backward(self, on=True):
         """Sorted variant: the reference's own (unclamped-colour undo) form of the alpha gradient (default off; gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_SORTED_REFERENCE_BACKWARD, 1 if on else 0), "set_option")

@@ -68,12 +68,14 @@ def algorithmic_bytes(st, kernel, end_bit):
         # Gaussian; 64-byte gradient row read, 12-byte RGB, and the 64-byte row zeroed again (replaces the per-step clear of the
         # whole gradient buffer) per Gaussian with tiles
         "optimizer": 1492 * N + (76 + 64) * V,
-        # split form (default at one view): the R rows in 64-row waves WITHOUT any tile (st["rows_in_waves_without_tiles"],
-        # counted from the tile counts of the last step) are updated by k_adam_rows_without_gradient on a side stream under the
-        # compositing kernels, k_sh_adam then walks the other N - R rows (V of them have a gradient row); both read every tile
-        # count (4 N)
-        "optimizer_late": 4 * N + 1488 * (N - st.get("rows_in_waves_without_tiles", N - V)) + (76 + 64) * V,
-        "optimizer_early": 4 * N + 1488 * st.get("rows_in_waves_without_tiles", N - V),
+        # split form (default at one view): R = st["side_stream_rows"] rows (whole 64-row waves: those without any tile, and part
+        # of those the forward walked no Gaussian of; counted by the library for the last step) are updated by
+        # k_adam_rows_without_gradient on a side stream under the compositing kernels, k_sh_adam then walks the other N - R rows
+        # (at most V of them have a gradient row); both read every tile count (4 N)
+        "optimizer_late": 4 * N + 1488 * (N - (st.get("side_stream_rows") or (N - V))) + (76 + 64) * min(V, N - (st.get("side_stream_rows") or (N - V))),
+        "optimizer_early": 4 * N + 1488 * (st.get("side_stream_rows") or (N - V)),
+        # its second launch alone: walks every row block once the forward's walked set is known (tile counts + one byte per wave)
+        "optimizer_early_2": 4 * N + N // 64 + 1488 * max(0, (st.get("side_stream_rows") or 0) - (st.get("side_stream_rows_first_launch") or 0)),
     }[kernel]
 
 
@@ -249,6 +251,8 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
     if args.full_sort:
         tracer.tracer_wrapper.set_lazy_tile_order(False)
+    if getattr(args, "early_extra", None) is not None:
+        tracer.tracer_wrapper.set_early_extra_percent(args.early_extra)
     if args.trainer == "native":
         native_mod = importlib.import_module("3dgrut_amd.native")
         model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree, spatial_order=not args.scene_order)
@@ -314,12 +318,6 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     ktimes, kcount = raster.kernel_times_mean()
     fb = raster.collect_times()
     stats = raster.stats()
-    cnt = raster.debug_buffer("tiles_count")
-    if cnt.numel():
-        pad = (-cnt.numel()) % 64
-        waves = torch.nn.functional.pad(cnt, (0, pad)).view(-1, 64)
-        empty = ~(waves != 0).any(1)
-        stats["rows_in_waves_without_tiles"] = int(empty.sum().item()) * 64 - (pad if bool(empty[-1]) else 0)
 
     # forward-only render time (reference's FPS definition: mean forward_render ms, threedgrut/render.py:231-251)
     with torch.no_grad():
@@ -362,6 +360,9 @@ def main():
     ap.add_argument("--fresh-optimizer-state", action="store_true",
                     help="start from all-zero Adam moments (step 0 of a training run) instead of the synthetic mid-training state "
                          "(non-zero moments on every row) the headline is measured in")
+    ap.add_argument("--early-extra", type=int, default=None,
+                    help="GUT_OPT_EARLY_EXTRA_PERCENT (0..100): share of the row blocks in which the side stream also takes the waves "
+                         "with tiles the forward walked nothing of (library default 25)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
                     help="one optimiser kernel after the backward instead of the early side-stream pass for the rows without tiles")
     args = ap.parse_args()
@@ -411,8 +412,9 @@ def main():
         W, H, fx = res["W"], res["H"], res["fx"]
         split = ktimes.get("optimizer_early", -1.0) > 0
         bkey = lambda k: "optimizer_late" if (k == "optimizer" and split) else k   # byte model of the kernel as launched
-        # dominant kernel = the longest one on the step's critical path (the early optimiser pass runs on a side stream
-        # under the compositing kernels and is reported under per_kernel only)
+        # dominant kernel = the longest single launch of the step ("optimizer_early" is the span of the side stream's two launches,
+        # idle gap included, and is reported under per_kernel only; "optimizer_early_2" is its second launch, timed with events
+        # on the side stream it runs on)
         dom = max((k for k in ktimes if ktimes[k] > 0 and k != "optimizer_early"), key=lambda k: ktimes[k])
         # achievable HBM bandwidth of THIS box, for context next to the 8 TB/s spec: device-to-device copy of 2 GB
         a = torch.empty(1 << 29, dtype=torch.float32, device=dev); b = torch.empty_like(a)
@@ -430,20 +432,26 @@ def main():
         # tracked profile of the same command and workload, and say so
         prof = profile_counters() if (args.workload == "bicycle_like_6M_1237x822" and not args.num_gaussians
                                       and args.trainer == "native" and not args.scene_order) else {}
-        pk = lambda k: prof.get("optimizer" if k == "optimizer" else k, {})
+        pk = lambda k: prof.get(k, {})
         traffic = pk(dom).get("hbm_bytes")
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": (prof.get("_source") + " (separate rocprofv3 --pmc passes of the same workload, replayed here)") if traffic else None,
                     "algorithmic_bytes": abytes, "mean_launch_ms": ktimes[dom], "launches_averaged": res["kcount"],
                     "box_copy_GBps": copy_gbs}
+        if dom == "optimizer_early_2":
+            roofline["note"] = ("side-stream optimiser pass, second launch: a persistent kernel of one workgroup per CU that streams the "
+                                "Adam state of the Gaussians the forward walked nothing of UNDER the VALU-bound backward compositor and "
+                                "then beside the pass over the walked waves; it shares the chip by design, alone it runs at the box's "
+                                "device-copy rate (profiles/: optimizer_early_2, PMC pass)")
         if split:
             # context for the split optimiser: what the whole Adam step must move vs what of it is left on the critical path
             roofline["optimizer_split"] = {
                 "whole_step_algorithmic_bytes": algorithmic_bytes(stats, "optimizer", stats["sort_end_bit"]),
                 "critical_path_kernel_bytes": algorithmic_bytes(stats, "optimizer_late", stats["sort_end_bit"]),
                 "side_stream_kernel_bytes": algorithmic_bytes(stats, "optimizer_early", stats["sort_end_bit"]),
-                "critical_path_ms": ktimes["optimizer"], "side_stream_span_ms": ktimes["optimizer_early"]}
+                "critical_path_ms": ktimes["optimizer"], "side_stream_span_ms": ktimes["optimizer_early"],
+                "side_stream_second_launch_ms": ktimes.get("optimizer_early_2")}
         per_kernel = {}
         for k in ktimes:
             e = {"ms": ktimes[k],
@@ -458,7 +466,8 @@ def main():
             if "hbm_bytes" in c:
                 e["traffic"] = c["hbm_bytes"]
             if k == "optimizer_early" and ktimes[k] > 0:
-                e["note"] = ("side stream, two launches (25 % of the row blocks under the forward compositor, 75 % under the backward "
+                e["note"] = ("side stream, two launches (waves without tiles of the first 25 % of the row blocks under the forward "
+                             "compositor; the rest of them plus every wave the forward walked nothing of from the start of the backward "
                              "compositor): ms is the span from the start of the first to the end of the second, idle gap included")
             per_kernel[k] = e
         sh_degree = 3

@@ -89,6 +89,9 @@ typedef struct GutStats {
     uint32_t sort_end_bit;       /* 32 + bit_width(T) */
     uint32_t binning_overflows;  /* forwards of this handle whose binning was redone because the frame had more intersections than
                                     the capacity assumed from earlier frames (the forward is queued before the count is known) */
+    uint64_t side_stream_rows;   /* Gaussians whose optimiser step the last gut_optimize_rows_without_gradient took (both of its
+                                    launches, whole 64-row waves); 0 when the last step did not use it */
+    uint64_t side_stream_rows_first_launch; /* ... of which in its first launch (under the forward compositor) */
 } GutStats;
 
 /* intermediate buffers exposed to the parity tests (device pointers into handle scratch, valid until
@@ -191,12 +194,20 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * composited max(colour, 0) (:159-161).  Identical to the default wherever no composited colour channel is negative; where one
  * is, the reference's gradient is not the derivative of its own forward (the default is).  For like-for-like comparisons. */
 #define GUT_OPT_SORTED_REFERENCE_BACKWARD 2
+/* GUT_OPT_EARLY_EXTRA_PERCENT (default 100, 0..100; unsorted variant): share of the 256-row blocks in which the second launch of
+ * gut_optimize_rows_without_gradient (queued when the backward compositor starts) also takes the 64-row waves that HAVE tiles
+ * but hold no Gaussian the forward compositor walked.  The backward compositor is bounded by the forward's per-tile depth, so
+ * such waves cannot receive a gradient; their zero-gradient Adam step is the same arithmetic wherever it runs.  0 = only waves
+ * without tiles take the side stream. */
+#define GUT_OPT_EARLY_EXTRA_PERCENT 3
 int gut_set_option(gut_handle h, int32_t option, int32_t value);
 
 /* per-kernel hipEvent timings of the last trace / trace_bwd (ms), for bench.py's roofline block.
  * Order: project, scan, expand, sort, ranges, render, render_bwd, project_bwd, optimizer (gut_optimize_after_bwd; -1 when
- * that call was not used), optimizer_early (gut_optimize_rows_without_gradient, timed on its side stream; -1 when not used).  Requires enable_kernel_timings; synchronises. */
-#define GUT_NUM_KERNEL_TIMERS 10
+ * that call was not used), optimizer_early (gut_optimize_rows_without_gradient on its side stream, start of its first to end of
+ * its second launch, idle gap included; -1 when not used), optimizer_early_2 (its second launch alone).  Requires
+ * enable_kernel_timings; synchronises. */
+#define GUT_NUM_KERNEL_TIMERS 11
 int gut_kernel_times(gut_handle h, float* ms8);
 /* mean per-kernel time over the (at most 64 most recent) trace/trace_bwd calls since the previous call of this
  * function; *count = number of forward calls averaged.  Synchronises. */
@@ -265,14 +276,19 @@ int gut_optimize_after_bwd(gut_handle h, void* stream, int32_t num_active_featur
                            const float* d_visibility, float* d_act12_out);
 
 /* Optional first half of that optimiser step, to be called BETWEEN gut_trace and gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) on
- * the forward's stream: the Gaussians the projection gave no tile (tiles_count == 0) receive an all-zero gradient whatever the
- * backward computes, so their Adam step (same arithmetic as gut_optimize_after_bwd: moments decay, parameters move on their
- * momentum, activation rows rewritten) is issued right away on a low-priority side stream owned by the handle, ordered behind
- * the projection kernel only.  It is pure HBM streaming and runs UNDER the VALU-bound compositing kernels of the same iteration;
- * the following gut_optimize_after_bwd (mandatory; same pointers and hyper-parameters; d_visibility must be NULL) then only
- * walks the rows that have tiles and orders the caller's stream behind the side stream.  The parameters after the two calls
- * are bit-identical to gut_optimize_after_bwd alone.  The caller must not touch the parameter tensors on other streams
- * between the two calls. */
+ * the forward's stream.  Gaussians that cannot receive a gradient from this view get their Adam step (same arithmetic as
+ * gut_optimize_after_bwd with an exactly-zero gradient: moments decay, parameters move on their momentum, activation rows
+ * rewritten) on a side stream owned by the handle, as pure HBM streaming UNDER and beside the VALU-bound compositing kernels of
+ * the same iteration.  They are taken by whole 64-row waves, in two launches of a persistent kernel with a small fixed footprint:
+ *   1. right away, ordered behind the binning part of the forward only: waves in which no row has a tile
+ *      (tiles_count == 0), in the first quarter of the row blocks;
+ *   2. when gut_trace_bwd_ex queues the backward compositor: the remaining waves without tiles and — unsorted variant,
+ *      GUT_OPT_EARLY_EXTRA_PERCENT — the waves that have tiles but hold no Gaussian among the list entries the forward
+ *      compositor walked (the backward compositor is bounded by the forward's per-tile depth).
+ * The following gut_optimize_after_bwd (mandatory; same pointers and hyper-parameters; d_visibility must be NULL) then walks only
+ * the other waves and orders the caller's stream behind the side stream.  The parameters after the two calls are those of
+ * gut_optimize_after_bwd alone; every row of a wave the side stream took is bit-identical to it.  The caller must not touch the
+ * parameter tensors on other streams between the two calls. */
 int gut_optimize_rows_without_gradient(gut_handle h, void* stream, float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48,
                                        float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* d_act12_out);

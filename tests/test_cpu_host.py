@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header():
     # sizes implied by include/gut_hip.h (natural alignment): GutCamera 2*4+2*8+6*4+2*4+4*4+4+2*28+(pad 4)+2*8
     assert C.sizeof(capi.GutCamera) == 152
     assert C.sizeof(capi.GutConfig) == 12 * 4 + 8 * 4
-    assert C.sizeof(capi.GutStats) == 7 * 8 + 8
+    assert C.sizeof(capi.GutStats) == 7 * 8 + 8 + 16
 
 
 def test_default_config_and_conf_mapping():

@@ -189,6 +189,31 @@ def _native_pair(n=20000, seed=21, **kw):
     return sc, steppers
 
 
+def _rows_in_unwalked_waves(raster, n):
+    """Boolean [n]: rows of 64-row waves that hold no Gaussian among the list entries the forward walked."""
+    ranges = raster.debug_buffer("tile_ranges").view(-1, 2).long()
+    trav = torch.minimum(raster.debug_buffer("tile_traversed_fwd").long(), ranges[:, 1] - ranges[:, 0])
+    ids = raster.debug_buffer("ordered_ids").long()
+    total = int(trav.sum())
+    tile_of = torch.repeat_interleave(torch.arange(trav.numel(), device=ids.device), trav)
+    off = torch.arange(total, device=ids.device) - torch.repeat_interleave(torch.cumsum(trav, 0) - trav, trav)
+    walked_ids = ids[ranges[:, 0][tile_of] + off]
+    walked_ids = walked_ids[(walked_ids >= 0) & (walked_ids < n)]
+    waves = torch.zeros((n + 63) // 64, dtype=torch.bool, device=ids.device)
+    waves[walked_ids // 64] = True
+    return ~waves.repeat_interleave(64)[:n]
+
+
+def exact_wave_mask(cnt, unwalked):
+    """Boolean [n]: rows of the waves the side stream owns with GUT_OPT_EARLY_EXTRA_PERCENT = 100: waves without any tile, and
+    waves (with tiles) the forward walked nothing of."""
+    n = cnt.numel()
+    pad = (-n) % 64
+    has = torch.nn.functional.pad(cnt != 0, (0, pad)).view(-1, 64).any(1)
+    unw = torch.nn.functional.pad(unwalked, (0, pad), value=True).view(-1, 64).all(1)
+    return ((~has) | unw).repeat_interleave(64)[:n]
+
+
 def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
     """gut_optimize_rows_without_gradient (rows without tiles, side stream, under the compositing kernels) followed by
     gut_optimize_after_bwd (rows with tiles) leaves EXACTLY the parameters, moments and activations of the one-pass kernel,
@@ -200,7 +225,8 @@ def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
     # cameras INSIDE the cloud looking in different directions: every view sees a different subset of the Gaussians
     dirs = [(1, 0, 0), (-1, 0.2, 0), (0, 1, 0.1), (0.1, -1, 0), (0, 0.1, 1)]
     views = [make_view("pinhole", W, H, cams.look_at_c2w((0.05 * k, 0.0, 0.02 * k), d), fx=140.0) for k, d in enumerate(dirs)]
-    some_without_tiles = 0
+    some_without_tiles = some_unwalked_with_tiles = 0
+    ovl.raster.set_early_extra_percent(100)
     state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48, act=st.act)
     for k, view in enumerate(views):
         # both start every step from the same bits (the rows WITH tiles pick up run-to-run differences in the last bits from
@@ -216,10 +242,19 @@ def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
         assert torch.equal(cnt, ref.raster.debug_buffer("tiles_count"))
         early = cnt == 0
         some_without_tiles += int(early.sum())
+        # rows of 64-row waves in which the forward walked no Gaussian cannot receive a gradient either (the backward is bounded
+        # by the forward's per-tile depth): the side stream's second launch takes those waves too, and they must come out
+        # bit-identical as well
+        unwalked = _rows_in_unwalked_waves(ovl.raster, cnt.numel())
+        assert torch.equal(unwalked, _rows_in_unwalked_waves(ref.raster, cnt.numel()))
+        some_unwalked_with_tiles += int((unwalked & ~early).sum())
+        exact = early | unwalked
         for name, t in state(ovl).items():
             r = state(ref)[name]
-            assert torch.equal(r[early], t[early]), f"step {k}: {name} (rows without tiles)"
-            assert torch.allclose(r[~early], t[~early], rtol=2e-5, atol=1e-7), f"step {k}: {name} (rows with tiles)"
+            assert torch.equal(r[exact], t[exact]), f"step {k}: {name} (rows that cannot receive a gradient)"
+            assert torch.allclose(r[~exact], t[~exact], rtol=2e-5, atol=1e-7), f"step {k}: {name} (rows in walked waves)"
+        st_ = ovl.raster.stats()
+        assert st_["side_stream_rows"] == int(exact_wave_mask(cnt, unwalked).sum()) and ref.raster.stats()["side_stream_rows"] == 0
         # rows that had a gradient earlier and have no tiles now keep moving on their momentum (dense Adam semantics)
         if k > 0:
             coasting = early & ever_tiles
@@ -233,7 +268,7 @@ def test_early_optimiser_pass_is_bit_identical_to_the_one_pass_kernel():
             assert not state(ovl)["m48"][dormant].any() and not state(ovl)["v12"][dormant].any()
         ever_tiles = (~early) if k == 0 else (ever_tiles | ~early)
         before = state(ovl)["raw"].clone()
-    assert some_without_tiles > 1000
+    assert some_without_tiles > 1000 and some_unwalked_with_tiles > 1000
     kt = ovl.raster.kernel_times()
     assert kt["optimizer_early"] > 0 and kt["optimizer"] > 0 and ref.raster.kernel_times()["optimizer_early"] < 0
 

@@ -50,7 +50,13 @@ def counters(pass_name):
         k = key_of(r["Kernel_Name"])
         if k:
             acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+    out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+    # the side-stream optimiser kernel is launched twice per step: report the step's total under optimizer_early and the second
+    # launch (the long one, under the backward compositor and after it) under optimizer_early_2
+    if "optimizer_early" in acc and all(len(v) == 2 for v in acc["optimizer_early"].values()):
+        out["optimizer_early"] = {c: sum(v) for c, v in acc["optimizer_early"].items()}
+        out["optimizer_early_2"] = {c: v[1] for c, v in acc["optimizer_early"].items()}
+    return out
 
 
 def kernel_durations(pass_name):
@@ -64,7 +70,11 @@ def kernel_durations(pass_name):
             k = key_of(r["Kernel_Name"])
             if k:
                 acc.setdefault(k, []).append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6)
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    out = {k: sum(v) / len(v) for k, v in acc.items()}
+    if len(acc.get("optimizer_early", [])) == 2:
+        out["optimizer_early"] = sum(acc["optimizer_early"])
+        out["optimizer_early_2"] = acc["optimizer_early"][1]
+    return out
 
 
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
@@ -143,7 +153,7 @@ L = ["# Profiles (" + rnd + ")\n",
      f"{plain['roofline'].get('box_copy_GBps', float('nan')):.0f} GB/s.\n",
      "Per-kernel counters (per launch):\n",
      "| kernel | duration ms (profiled) | HBM bytes (2xFETCH+WRITE) | uncorrected | VALU wave-instr | valu_issue_frac | valu_active_frac | LDS instr | bank-conflict cycles | atomic GB/s |\n|---|---|---|---|---|---|---|---|---|---|"]
-for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimizer", "optimizer_early"):
+for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimizer", "optimizer_early", "optimizer_early_2"):
     e, t = sq["kernels"].get(k, {}), traffic["kernels"].get(k, {})
     if not e and not t:
         continue
@@ -151,8 +161,8 @@ for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimize
     L.append(f"| {k} | {g(e, 'duration_ms_SQ_A', '{:.3f}')} | {g(t, 'hbm_bytes', '{:.3e}')} | {g(t, 'hbm_bytes_uncorrected', '{:.3e}')} | "
              f"{g(e, 'SQ_INSTS_VALU', '{:.3e}')} | {g(e, 'valu_issue_frac', '{:.2f}')} | {g(e, 'valu_active_frac', '{:.2f}')} | "
              f"{g(e, 'SQ_INSTS_LDS', '{:.3e}')} | {g(e, 'SQ_LDS_BANK_CONFLICT', '{:.3e}')} | {g(e, 'atomic_GBps', '{:.0f}')} |")
-L += ["", "`optimizer_early` is launched twice per step (25 % / 75 % of the row blocks): its row is the mean of the two launches, "
-          "double it for the per-step total.",
+L += ["", "`optimizer_early` is the side-stream optimiser kernel, launched twice per step: its row is the step's total (both launches, "
+          "run alone here because the PMC passes serialise the kernels), `optimizer_early_2` the second launch.",
       "", "Top kernels (all launches of the run: 25 train steps + 10 render-only frames + setup):\n",
       "| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|"]
 for r in rows[:18]:
