@@ -68,7 +68,7 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
            "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
            "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_compact_gradient_rows", "gut_scatter_gradient_records",
-           "gut_sh_adam_step_ex", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
+           "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
 
 _lib = None
 
@@ -122,7 +122,9 @@ def load():
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
                                      C.c_float, C.c_float, C.c_float, u32, vp, vp, u32]
-    lib.gut_sh_adam_step_ex.argtypes = lib.gut_sh_adam_step.argtypes + [u32]
+    lib.gut_sh_adam_step_ex.argtypes = lib.gut_sh_adam_step.argtypes + [u32, vp]
+    lib.gut_mark_walked_waves.argtypes = [vp, vp, vp]
+    lib.gut_adam_unwalked_waves.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float, u32, vp]
     lib.gut_compact_gradient_rows.argtypes = [vp, vp, vp, vp, u32, vp]
     lib.gut_scatter_gradient_records.argtypes = [vp, vp, u32, u32, vp, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:

@@ -762,6 +762,27 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     return 0;
 }
 
+int gut_mark_walked_waves(gut_handle h, void* stream_, uint8_t* d_wave_flags) {
+    if (!h) return fail("gut_mark_walked_waves: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (!h->have_forward || h->fwd_stream != s)
+        return fail("gut_mark_walked_waves: no forward context on this stream (call gut_trace first, same stream)");
+    if (h->n == 0) return 0;
+    if (!d_wave_flags) return fail("gut_mark_walked_waves: null pointer argument");
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
+    HIP_TRY(hipMemsetAsync(d_wave_flags, 0, ((size_t)h->n + 63) / 64, s));
+    if (h->m == 0) return 0;
+    if (h->cfg.k_buffer_size > 0)   // sorted variant: its backward is not bounded by the forward's depth -> every wave with a tile
+        gut::launch_mark_waves_with_tiles(s, h->n, h->tiles_count.as<uint32_t>(), d_wave_flags);
+    else
+        gut::launch_mark_walked_waves(s, h->n, (uint32_t)h->tiles, h->ranges.as<uint32_t>(), h->trav_fwd.as<uint32_t>(),
+                                      (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(), d_wave_flags);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int gut_compact_gradient_rows(gut_handle h, void* stream_, const float* d_particle_density, float* d_records, uint32_t capacity,
                               uint32_t* d_count) {
     if (!h) return fail("gut_compact_gradient_rows: null handle");

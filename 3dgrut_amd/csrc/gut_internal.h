@@ -108,6 +108,7 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
                                        const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end, bool second_launch);
 void launch_count_side_stream_rows(hipStream_t s, uint32_t n, const uint32_t* tiles_count, const uint8_t* wave_walked,
                                    uint32_t split_block, uint32_t extra_end, Counters* out);
+void launch_mark_waves_with_tiles(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint8_t* wave_flags);
 void launch_mark_walked_waves(hipStream_t s, uint32_t n, uint32_t tiles, const uint32_t* ranges, const uint32_t* tile_walked,
                               const uint32_t* ids, uint8_t* wave_walked);
 void launch_stats_reduce(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint32_t t, const uint32_t* trav_fwd,

@@ -217,6 +217,8 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
     if (kScratch && sp.rows_with_tiles_only &&
         side_stream_owns_wave(sp.own, __ballot(i < sp.n && tiles_count[i] != 0) != 0ull, wave_first >> 6, blockIdx.x))
         return;
+    // data-parallel runs: waves no rank's forward walked were updated by gut_adam_unwalked_waves (wave-uniform test)
+    if (!kScratch && sp.own.walked && wave_first < sp.n && sp.own.walked[wave_first >> 6] == 0) return;
     float G[48];
 #pragma unroll
     for (int k = 0; k < 48; ++k) G[k] = 0.0f;
@@ -373,7 +375,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         // (sub-pixel or transparent), sprinkled between rows that have: row-granular, this pass visited 55 k such waves for
         // 13 % of its bytes with mostly-masked loads, and both passes touched those waves' cache lines.
         const bool mine = i < n;
-        if (!side_stream_owns_wave(own, __ballot(i < n && tiles_count[i] != 0) != 0ull, wave_first >> 6, blk, second_launch != 0u)) continue;
+        // (tiles_count == nullptr: ownership by the wave flags alone — data-parallel runs, where the flags are the union over the
+        //  ranks' views of the walked waves)
+        const bool has_tiles = tiles_count ? (__ballot(i < n && tiles_count[i] != 0) != 0ull) : true;
+        if (!side_stream_owns_wave(own, has_tiles, wave_first >> 6, blk, second_launch != 0u)) continue;
         if (mine) {
             // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
             // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
@@ -594,6 +599,18 @@ void launch_count_side_stream_rows(hipStream_t s, uint32_t n, const uint32_t* ti
     hipLaunchKernelGGL(k_count_side_stream_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, tiles_count, own, out);
 }
 
+__global__ __launch_bounds__(kBlock) void k_mark_waves_with_tiles(uint32_t n, const uint32_t* __restrict__ tiles_count,
+                                                                 uint8_t* __restrict__ wave_flags) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool has = __ballot(i < n && tiles_count[i] != 0) != 0ull;
+    if ((threadIdx.x & 63) == 0 && i < n && has) wave_flags[i >> 6] = 1;
+}
+
+void launch_mark_waves_with_tiles(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint8_t* wave_flags) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_mark_waves_with_tiles, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, tiles_count, wave_flags);
+}
+
 void launch_mark_walked_waves(hipStream_t s, uint32_t n, uint32_t tiles, const uint32_t* ranges, const uint32_t* tile_walked,
                               const uint32_t* ids, uint8_t* wave_walked) {
     if (n == 0 || tiles == 0) return;
@@ -653,7 +670,7 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
                         float* d_mrgb, float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
                         float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
                         float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out,
-                        uint32_t mrgb_view_stride, uint32_t flags) {
+                        uint32_t mrgb_view_stride, uint32_t flags, const uint8_t* d_wave_flags) {
     if (num_particles == 0) return 0;
     if (!d_camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
         !lr12 || !lr48)
@@ -667,7 +684,7 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
     sp.n = num_particles; sp.views = num_views; sp.sh_degree = sh_degree; sp.grad_scale = grad_scale;
     sp.view_stride = mrgb_view_stride ? mrgb_view_stride : num_particles;
     sp.rows_with_tiles_only = 0;
-    sp.own.walked = nullptr; sp.own.split_block = 0; sp.own.extra_end = 0;
+    sp.own.walked = d_wave_flags; sp.own.split_block = 0; sp.own.extra_end = 0;
     sp.clear_consumed = (flags & GUT_ADAM_CLEAR_CONSUMED_GRADS) ? 1 : 0;
     if (sp.view_stride < num_particles) return 3;
     hipLaunchKernelGGL(gut::k_sh_adam<false>, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
@@ -685,7 +702,19 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
                      uint32_t mrgb_view_stride) {
     return gut_sh_adam_step_ex(stream, num_particles, sh_degree, num_views, d_camera_positions, const_cast<float*>(d_mrgb),
                                const_cast<float*>(d_raw_grad12), grad_scale, d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12,
-                               lr48, beta1, beta2, eps, step, d_visibility, d_act12_out, mrgb_view_stride, 0u);
+                               lr48, beta1, beta2, eps, step, d_visibility, d_act12_out, mrgb_view_stride, 0u, nullptr);
+}
+
+int gut_adam_unwalked_waves(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
+                            float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                            float beta1, float beta2, float eps, uint32_t step, float* d_act12_out) {
+    if (num_particles == 0) return 0;
+    if (!d_wave_flags || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48) return 1;
+    const uint32_t nblocks = (num_particles + gut::kBlock - 1) / gut::kBlock;
+    gut::launch_adam_rows_without_gradient(static_cast<hipStream_t>(stream), num_particles, nullptr, d_raw12, d_raw_m, d_raw_v, d_sh48,
+                                           d_sh_m, d_sh_v, lr12, lr48, beta1, beta2, eps, step, d_act12_out, 0, nblocks, d_wave_flags,
+                                           0, nblocks, true);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 int gut_scatter_gradient_records(void* stream, const float* d_records, uint32_t count, uint32_t num_particles, float* d_raw_grad12,

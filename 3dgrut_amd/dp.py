@@ -11,6 +11,11 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    def wait(self):
+        return None
+
+
 def _skip(world: int) -> bool:
     """World 1 needs no exchange.  GUT_DP_FORCE_COLLECTIVES=1 (with an initialised process group) still issues every
     collective so the RCCL call sequence can be exercised on a one-GPU box (bench.py --force-exchange)."""
@@ -57,6 +62,18 @@ def allreduce_max_(tensor, world: int, group=None):
             tensor.copy_(h)
         else:
             dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group)
+
+
+def allreduce_max_async(tensor, world: int, group=None):
+    """MAX all-reduce in place; returns an object with .wait() (orders the CURRENT stream behind the collective)."""
+    if _skip(world):
+        return _Done()
+    if _stage_on_cpu(tensor, group):
+        h = tensor.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        tensor.copy_(h)
+        return _Done()
+    return dist.all_reduce(tensor, op=dist.ReduceOp.MAX, group=group, async_op=True)
 
 
 def allreduce_sum_async(tensor, world: int, group=None):

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .dp import exchange_gradient_records, allgather_rows_, allgather_rows_async, allreduce_max_, allreduce_mean_, allreduce_sum_async
+from .dp import allreduce_max_async, exchange_gradient_records, allgather_rows_, allgather_rows_async, allreduce_max_, allreduce_mean_, allreduce_sum_async
 from .losses import photometric_loss
 from .tracer import SplatRaster, Tracer
 
@@ -112,7 +112,7 @@ class NativeTrainStep:
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
                  betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2,
                  dp_chunks=4, dp_chunk_min_rows=1 << 20, fuse_epilogue=True, schedule=None,
-                 overlap_optimizer=None, dp_exchange="sparse"):
+                 overlap_optimizer=None, dp_exchange="sparse", dp_side_stream=True):
         self.model = model
         self.tracer = tracer
         self.raster: SplatRaster = tracer.tracer_wrapper
@@ -162,6 +162,11 @@ class NativeTrainStep:
         if dp_exchange not in ("sparse", "dense"):
             raise ValueError("dp_exchange must be 'sparse' or 'dense'")
         self.dp_exchange = dp_exchange
+        # sparse exchange only: the ranks MAX-reduce one byte per 64-row wave ("my forward walked a Gaussian of this wave") and the
+        # waves no view walked get their zero-gradient Adam step on a side stream, under the backward compositor and the exchange
+        # (gut_mark_walked_waves / gut_adam_unwalked_waves); off with SelectiveAdam, whose mask that kernel does not take
+        self.dp_side_stream = bool(dp_side_stream) and not selective
+        self._side = None
         self.lambda_l1, self.lambda_ssim = float(lambda_l1), float(lambda_ssim)
         self._loss_ws = None
         self._loss3 = None
@@ -203,6 +208,7 @@ class NativeTrainStep:
                 self.records = torch.empty((max(n, 1), _capi.GRADIENT_RECORD_FLOATS), dtype=torch.float32, device=dev)
                 self.rec_count = torch.zeros(1, dtype=torch.int32, device=dev)
                 self._rec_scratch = {}
+                self.wave_flags = torch.zeros(((n + 63) // 64,), dtype=torch.uint8, device=dev)
                 self.exchanged_records = 0     # records received in the last step, all views (diagnostics / bench)
             else:
                 self.mrgb = [torch.empty((w, r1 - r0, 3), dtype=torch.float32, device=dev) for r0, r1 in self.chunks]
@@ -440,7 +446,33 @@ class NativeTrainStep:
         """Backward + sparse gradient exchange + optimiser of a data-parallel step (dp_exchange == "sparse")."""
         m = self.model
         n = m.num_gaussians
+        f32p = C.POINTER(C.c_float)
+        main = torch.cuda.current_stream(m.raw.device)
+        side_on = self.dp_side_stream and n > 0
+        if side_on:
+            # one byte per wave: did THIS view's forward walk a Gaussian of it?  MAX over the ranks while the backward runs.
+            rc = self._lib.gut_mark_walked_waves(self.raster._handle, C.c_void_p(main.cuda_stream), self.wave_flags.data_ptr())
+            _capi.check(rc, "mark_walked_waves")
+            flags_ready = torch.cuda.Event()
+            flags_ready.record(main)               # BEFORE the backward is queued: the side stream must not wait for it
+            flags_work = allreduce_max_async(self.wave_flags, w) if exchange else None
         self.raster.trace_bwd(*bwd_args, skip_epilogue=True)
+        if side_on:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=m.raw.device)
+            self._side.wait_event(flags_ready)
+            with torch.cuda.stream(self._side):
+                if flags_work is not None:
+                    flags_work.wait()
+                rc = self._lib.gut_adam_unwalked_waves(
+                    C.c_void_p(self._side.cuda_stream), n, self.wave_flags.data_ptr(), m.raw.data_ptr(), self.m12.data_ptr(),
+                    self.v12.data_ptr(), m.features.data_ptr(), self.m48.data_ptr(), self.v48.data_ptr(),
+                    self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p), self.betas[0], self.betas[1], self.eps,
+                    self.step_id + 1, self.act.data_ptr())
+                if rc:
+                    raise RuntimeError(f"[3dgut] adam_unwalked_waves failed ({rc})")
+            if flags_work is not None:
+                flags_work.wait()                  # the main stream's optimiser call reads the reduced flags too
         self.raster.compact_gradient_rows(self.act, self.records, self.rec_count)
         self._mark(evs)
         cam_local = self._sensor_position(batch)
@@ -466,15 +498,16 @@ class NativeTrainStep:
                 if rc:
                     raise RuntimeError(f"[3dgut] scatter_gradient_records failed ({rc})")
         vmask = vis.reshape(-1) if self.selective else None
-        f32p = C.POINTER(C.c_float)
         rc = self._lib.gut_sh_adam_step_ex(
             C.c_void_p(st), n, m.n_active_features, w, self.cams.data_ptr(), slabs.data_ptr(), self.g12.data_ptr(), 1.0 / w,
             m.raw.data_ptr(), self.m12.data_ptr(), self.v12.data_ptr(), m.features.data_ptr(), self.m48.data_ptr(),
             self.v48.data_ptr(), self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p), self.betas[0], self.betas[1],
             self.eps, 0 if self.selective else self.step_id + 1, None if vmask is None else vmask.data_ptr(), self.act.data_ptr(),
-            n, _capi.ADAM_CLEAR_CONSUMED_GRADS)
+            n, _capi.ADAM_CLEAR_CONSUMED_GRADS, self.wave_flags.data_ptr() if side_on else None)
         if rc:
             raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
+        if side_on:
+            main.wait_stream(self._side)           # the next forward reads every row
         self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
 
     def _end_of_step(self, evs):

@@ -259,7 +259,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
         stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
                                              rank=rank, fused_sh_adam=not args.dense_exchange,
                                              overlap_optimizer=False if args.no_overlap_optimizer else None,
-                                             dp_exchange=args.dp_exchange)
+                                             dp_exchange=args.dp_exchange, dp_side_stream=not args.no_dp_side_stream)
         if not getattr(args, "fresh_optimizer_state", False):
             # Synthetic MID-TRAINING optimiser state, like the synthetic parameters: every row has non-zero Adam moments, as every
             # Gaussian of a trained 6 M scene has (a moment only returns to exact zero after thousands of gradient-free steps),
@@ -347,6 +347,8 @@ def main():
     ap.add_argument("--dp-exchange", default="sparse", choices=["sparse", "dense"],
                     help="N>1 (native trainer, compact exchange): sparse = 64-byte records of the Gaussians each view gave a gradient "
                          "to (all-gather of max-count records per rank); dense = all-reduce [N,12] + all-gather [N,3] per view")
+    ap.add_argument("--no-dp-side-stream", action="store_true",
+                    help="N>1, sparse exchange: do not update the waves no view walked on a side stream under the backward / exchange")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: initialise RCCL with world size 1 and issue the data-parallel collectives anyway "
                          "(exercises the N>1 call sequence on a one-GPU box; the number is NOT a bench line)")

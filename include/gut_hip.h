@@ -320,7 +320,23 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
                         const float* d_camera_positions, float* d_mrgb, float* d_raw_grad12, float grad_scale,
                         float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
                         const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
-                        const float* d_visibility, float* d_act12_out, uint32_t mrgb_view_stride, uint32_t flags);
+                        const float* d_visibility, float* d_act12_out, uint32_t mrgb_view_stride, uint32_t flags,
+                        const uint8_t* d_wave_flags /* may be NULL; else waves with flag 0 are left alone, see below */);
+
+/* Data-parallel form of the side-stream optimiser pass (single-view form: gut_optimize_rows_without_gradient).
+ * gut_mark_walked_waves: after gut_trace, same stream: d_wave_flags [ceil(N/64)] bytes := 1 for every 64-row wave that holds a
+ *   Gaussian among the list entries the forward compositor walked (sorted variant: every wave with a tile), else 0.  The
+ *   backward compositor gives gradients to those Gaussians only.  MAX-all-reduce the flags over the ranks (94 KB at 6 M): a
+ *   wave whose flag is still 0 receives no gradient from ANY view of the step.
+ * gut_adam_unwalked_waves: zero-gradient Adam step (moments decay, parameters move on their momentum, activation rows
+ *   rewritten) of every wave whose flag is 0, as a persistent kernel with a small fixed footprint: queue it on a side stream
+ *   as soon as the reduced flags are there; it streams under the backward compositor, the gradient exchange and the call below.
+ * gut_sh_adam_step_ex(..., d_wave_flags) then skips exactly those waves.  Rows of the skipped waves are bit-identical to what
+ *   gut_sh_adam_step_ex without flags computes for them (their gradient is exactly zero). */
+int gut_mark_walked_waves(gut_handle h, void* stream, uint8_t* d_wave_flags);
+int gut_adam_unwalked_waves(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
+                            float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                            float beta1, float beta2, float eps, uint32_t step, float* d_act12_out);
 
 /* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */
