@@ -344,8 +344,8 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
 // everything else and are never queued behind a wall of streaming workgroups (a one-block-per-256-rows grid on a low-priority
 // stream starved the image-sized loss kernels: measured 0.14 -> 0.8 ms).  One wave per SIMD: the raw row's nine 16-byte loads
 // are issued together, the [N,48] sweep issues three per (p, m, v) group and the next group's loads behind the previous
-// group's stores.  Issuing all twelve loads of four groups before the first use was measured (105 VGPRs): no faster, and one
-// more register block taken from the compositor next door; two waves per SIMD at half the registers moved the same bytes but
+// group's stores.  Issuing the loads of 2 / 4 / 6 groups before the first use was measured twice (84–116 VGPRs, which still
+// leaves the compositors their waves): no faster — the pass is not latency-bound, beside the compositors or alone; two waves per SIMD at half the registers moved the same bytes but
 // spilled to scratch at the 64-VGPR bound (this form has no scratch).  Skipping the stores of groups whose moments are all
 // zero (fixed points of the update) made the start of a training run 4 % faster and its steady state 8 % slower (the test
 // sits between the loads and their use): not kept.

@@ -357,6 +357,38 @@ def test_sparse_exchange_step_equals_the_one_pass_step():
         assert rel_l2(a.cpu().numpy(), b_.cpu().numpy()) <= 2e-5
 
 
+def test_walked_wave_flags_match_the_walked_list_prefixes():
+    """gut_mark_walked_waves: flag[w] == 1 exactly for the 64-row waves that hold a Gaussian among the first
+    tile_traversed_fwd[tile] entries of some tile's ordered list — and every Gaussian the backward gives a gradient to lies in
+    such a wave (the backward compositor is bounded by the forward's depth)."""
+    sc = scenes.scene_c1(20000, 23)
+    W, H = 160, 120
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.05, 0.0, 0.02), (1, 0, 0)), fx=140.0)   # camera inside the cloud
+    model = native.NativeGaussianModel(sc, device=DEV)
+    st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, fuse_epilogue=False)
+    b = to_batch(view, DEV)
+    rgba, dist_, hits, vis = st.forward(b)
+    n = model.num_gaussians
+    flags = torch.full(((n + 63) // 64,), 7, dtype=torch.uint8, device=DEV)
+    s_ = torch.cuda.current_stream().cuda_stream
+    assert st._lib.gut_mark_walked_waves(st.raster._handle, C.c_void_p(s_), flags.data_ptr()) == 0
+    unwalked_rows = _rows_in_unwalked_waves(st.raster, n)
+    expect = ~torch.nn.functional.pad(unwalked_rows, (0, (-n) % 64), value=True).view(-1, 64).all(1)
+    assert torch.equal(flags.bool(), expect) and int(flags.max()) == 1
+    assert 0 < int(expect.sum()) < expect.numel()
+    # gradients only inside flagged waves
+    _, sensor, poses, _, _ = st._ctx
+    m = st.model
+    rgba_grad = torch.randn(rgba.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    args = (st.step_id, m.n_active_features, st.act, m.features, b.rays_ori.contiguous(), b.rays_dir.contiguous(), None, sensor,
+            poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_grad,
+            dist_, None)
+    g12 = torch.empty((n, 12), device=DEV); mrgb = torch.empty((n, 3), device=DEV)
+    st.raster.trace_bwd(*args, raw_parameter_grads=True, compact_radiance_grads=True, out=(g12, mrgb))
+    has_grad = (g12.abs().sum(1) + mrgb.abs().sum(1)) > 0
+    assert int(has_grad.sum()) > 0 and not bool((has_grad & unwalked_rows).any())
+
+
 def test_half_applied_optimiser_step_is_an_error():
     sc, (_, ovl) = _native_pair(n=500)
     view = make_view("pinhole", 64, 48, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64.0)
