@@ -441,6 +441,11 @@ def main():
                     "traffic_source": (prof.get("_source") + " (separate rocprofv3 --pmc passes of the same workload, replayed here)") if traffic else None,
                     "algorithmic_bytes": abytes, "mean_launch_ms": ktimes[dom], "launches_averaged": res["kcount"],
                     "box_copy_GBps": copy_gbs}
+        if pk(dom).get("duration_ms_SQ_A"):
+            # the same kernel with nothing beside it: rocprofv3's PMC passes serialise the launches (tracked profile, replayed)
+            roofline["alone_in_profile"] = {"ms": pk(dom)["duration_ms_SQ_A"], "hbm_bytes": traffic,
+                                            "frac": (traffic or abytes) / (pk(dom)["duration_ms_SQ_A"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "source": prof.get("_source")}
         if dom == "optimizer_early_2":
             roofline["note"] = ("side-stream optimiser pass, second launch: a persistent kernel of one workgroup per CU that streams the "
                                 "Adam state of the Gaussians the forward walked nothing of UNDER the VALU-bound backward compositor and "
