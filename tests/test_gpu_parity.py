@@ -236,6 +236,19 @@ def test_error_behaviour():
         raster.trace(0, 3, d12.double(), sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
     with pytest.raises(RuntimeError):  # unsupported variant is rejected, not silently rendered
         gut.SplatRaster({"render": {"splat": {"k_buffer_size": 17}}})
+    # the data-parallel helpers need their context too
+    import ctypes as C
+    lib = raster._lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    flags = torch.zeros(4, dtype=torch.uint8, device=DEV)
+    assert lib.gut_mark_walked_waves(raster._handle, st, flags.data_ptr()) != 0       # no forward yet
+    rec = torch.zeros((4, 16), device=DEV); cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="no backward context"):
+        raster.compact_gradient_rows(d12, rec, cnt)
+    with pytest.raises(ValueError):
+        raster.compact_gradient_rows(d12, torch.zeros((3, 16), device=DEV), cnt)       # fewer record slots than particles
+    with pytest.raises(RuntimeError):
+        raster.set_early_extra_percent(101)
     sensor.cam.shutter = 7  # not a ShutterType
     with pytest.raises(RuntimeError):
         raster.trace(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
