@@ -303,6 +303,9 @@ class NativeTrainStep:
             for k in range(len(names)):
                 acc[k] += evs[k].elapsed_time(evs[k + 1])
         n = len(self._phase_events)
+        # whole steps, event to event (GPU time incl. any wait for the host): the slowest one shows a one-off stall
+        spans = sorted(evs[0].elapsed_time(evs[len(names)]) for evs in self._phase_events)
+        self.last_step_spans_ms = dict(min=spans[0], median=spans[len(spans) // 2], max=spans[-1])
         if reset:
             self._phase_events = []
         return {names[k]: acc[k] / n for k in range(len(names))}

@@ -325,7 +325,8 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
             stepper.render(batch_for(s), train=False)
     torch.cuda.synchronize(dev)
     render_ms = raster.collect_times().get("forward_render", float("nan"))
-    return dict(value=world * steps / elapsed, ms_per_step=1000.0 * elapsed / steps, phases=phases, ktimes=ktimes, kcount=kcount, fb=fb,
+    return dict(value=world * steps / elapsed, ms_per_step=1000.0 * elapsed / steps, phases=phases,
+                step_spans=getattr(stepper, "last_step_spans_ms", None), ktimes=ktimes, kcount=kcount, fb=fb,
                 stats=stats, render_ms=render_ms, scene=scene, cams=cams, pose_mod=pose_mod, c2ws=c2ws, W=W, H=H, fx=fx,
                 fisheye=fisheye, stepper=stepper)
 
@@ -499,7 +500,7 @@ def main():
                                                       if getattr(stepper, "_overlap_probe", None) else None)},
             "render_ms_per_frame": res["render_ms"],
             "forward_render_ms_in_train": res["fb"].get("forward_render"), "backward_render_ms_in_train": res["fb"].get("backward_render"),
-            "phase_ms": res["phases"], "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
+            "phase_ms": res["phases"], "step_gpu_span_ms": res["step_spans"], "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
             "reference_rtx5090": {"images_per_s": 31.6, "render_ms": 3.64, "note": "README.md:320, different hardware, real dataset"},
         }
         if world == 1 and not args.no_cpu_baseline:
