@@ -329,26 +329,25 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
     }
 }
 
-// k_adam_rows_without_gradient: rows k_sh_adam<true> would update with an all-zero gradient — Gaussians the projection
-// gave no tile (tiles_count == 0: culled, off-screen, transparent) — need nothing from the backward pass.  This pass takes
-// them by WHOLE WAVES of 64 rows (those in which no row has a tile); rows without tiles inside other waves stay with
-// k_sh_adam<true>, which sees their zero gradient.  Their Adam step
-// (moments decay, parameters keep moving on their momentum, exactly as torch.optim.Adam does with a zero gradient) is
-// pure HBM streaming, so it runs on a low-priority side stream UNDER the VALU-bound compositing kernels of the same
-// iteration; k_sh_adam<true> then only walks the rows that have tiles.  Same adam4 arithmetic, same activation: the
-// parameters after the step are bit-identical to the one-pass kernel's.  One wave per 64 Gaussians; the [N,48] sweep is the
-// same coalesced 16-byte pattern with a per-row predicate taken from the wave's ballot.
-// Launch shape: PERSISTENT with a fixed, small footprint — gridDim.x = 1 workgroup per CU (one wave per SIMD, 78 VGPRs, 192 B
-// of LDS), every workgroup striding over the 256-row blocks.  It is queued in front of the compositing kernel, so its
-// workgroups take their wave slot per SIMD first and keep it until the pass is done; the compositing and loss kernels get
-// everything else and are never queued behind a wall of streaming workgroups (a one-block-per-256-rows grid on a low-priority
-// stream starved the image-sized loss kernels: measured 0.14 -> 0.8 ms).  One wave per SIMD: the raw row's nine 16-byte loads
-// are issued together, the [N,48] sweep issues three per (p, m, v) group and the next group's loads behind the previous
-// group's stores.  Issuing the loads of 2 / 4 / 6 groups before the first use was measured twice (84–116 VGPRs, which still
-// leaves the compositors their waves): no faster — the pass is not latency-bound, beside the compositors or alone; two waves per SIMD at half the registers moved the same bytes but
-// spilled to scratch at the 64-VGPR bound (this form has no scratch).  Skipping the stores of groups whose moments are all
-// zero (fixed points of the update) made the start of a training run 4 % faster and its steady state 8 % slower (the test
-// sits between the loads and their use): not kept.
+// k_adam_rows_without_gradient: the Adam step of Gaussians that cannot receive a gradient from the current view — the ones the
+// projection gave no tile (tiles_count == 0: culled, off-screen, transparent) and, once the forward compositor has run, the
+// ones it walked nothing of (EarlyOwnership above) — needs nothing from the backward pass.  It is the zero-gradient update
+// (moments decay, parameters keep moving on their momentum, exactly as torch.optim.Adam does with a zero gradient), pure HBM
+// streaming, so it runs on a side stream UNDER and beside the VALU-bound compositing kernels of the same iteration;
+// k_sh_adam<true> then only walks the remaining waves.  Ownership is by WHOLE WAVES of 64 rows; rows without tiles inside
+// other waves stay with k_sh_adam<true>, which sees their zero gradient.  Same adam4 arithmetic, same activation: every row
+// this pass updates is bit-identical to the one-pass kernel's.  One wave per 64 Gaussians; the [N,48] sweep is the same
+// coalesced 16-byte pattern as in k_sh_adam.
+// Launch shape: PERSISTENT with a fixed, small footprint — gridDim.x = 1 workgroup per CU (one wave per SIMD, 83 VGPRs, 192 B
+// of LDS, no scratch), every workgroup striding over the 256-row blocks.  Its workgroups take their wave slot per SIMD once and
+// keep it until the pass is done; the compositing and loss kernels get everything else and are never queued behind a wall of
+// streaming workgroups (a one-block-per-256-rows grid on a low-priority stream starved the image-sized loss kernels: measured
+// 0.14 -> 0.8 ms).  The raw row's nine 16-byte loads are issued together, the [N,48] sweep issues three per (p, m, v) group and
+// the next group's loads behind the previous group's stores.  Measured and not kept: the loads of 2 / 4 / 6 groups issued before
+// the first use (84-116 VGPRs, which still leaves the compositors their waves): no faster, beside the compositors or alone —
+// the pass is not latency-bound; two waves per SIMD at half the registers: same bytes, but scratch at the 64-VGPR bound;
+// skipping the stores of groups whose moments are all zero (fixed points of the update): the start of a training run 4 %
+// faster, its steady state 8 % slower (the test sits between the loads and their use).
 __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamParams a12, AdamParams a48, uint32_t n,
                                                                           const uint32_t* __restrict__ tiles_count,
                                                                           float4* __restrict__ p12, float4* __restrict__ m12,
