@@ -369,7 +369,7 @@ struct AccLayout {
 };
 
 template <bool kDistGrad>
-__global__ __launch_bounds__(kBlock, 4) void k_render_backward(ViewParams v, RenderConsts c,
+__global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(ViewParams v, RenderConsts c,
                                                            const float4* __restrict__ density12,
                                                            const float* __restrict__ feat,
                                                            const float* __restrict__ ray_ori,
