@@ -141,10 +141,12 @@ class NativeTrainStep:
         self.fused = bool(fused_sh_adam)
         self.fused_loss = bool(fused_loss)
         self.fuse_epilogue = bool(fuse_epilogue)
-        # one view, fused epilogue: the Adam step of the Gaussians without tiles (no gradient this iteration) runs on a
-        # low-priority side stream under the compositing kernels (SplatRaster.optimize_rows_without_gradient)
-        # Default: on when the model keeps its rows in spatial order (measured on the 6 M-Gaussian bench frame: -9 % step time
-        # with Morton-ordered rows, +3 % with randomly ordered ones, where both passes end up touching most 128-byte blocks).
+        # one view, fused epilogue: the Adam step of the 64-row waves that cannot receive a gradient from the view (no tile, or
+        # nothing of the wave among the list entries the forward walked) runs on a side stream of the handle, under and beside
+        # the compositing kernels (SplatRaster.optimize_rows_without_gradient)
+        # Default: on when the model keeps its rows in spatial order — whole waves only qualify where such Gaussians are stored
+        # next to each other (6 M-Gaussian bench frame, Morton-ordered rows: 3.66 -> 3.0 ms per step; with randomly ordered rows
+        # hardly a wave qualifies).
         # Below ~1 M Gaussians the optimiser is a few percent of the step and the side-stream pass only costs (lego-like 300 k:
         # 877 -> 851 images/s), so the default also asks for a model of that size.
         self.overlap_optimizer = (bool(getattr(model, "spatial_order", False)) and model.num_gaussians >= self.OVERLAP_MIN_GAUSSIANS) \

@@ -367,7 +367,7 @@ def main():
                     help="GUT_OPT_EARLY_EXTRA_PERCENT (0..100): share of the row blocks in which the side stream also takes the waves "
                          "with tiles the forward walked nothing of (library default 25)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
-                    help="one optimiser kernel after the backward instead of the early side-stream pass for the rows without tiles")
+                    help="one optimiser kernel after the backward instead of the side-stream pass for the waves that cannot receive a gradient")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
