@@ -212,3 +212,57 @@ def test_two_pass_optimiser_at_full_size_with_finely_interleaved_rows():
                 assert float((a - b).abs().max()) <= 0.12, f"step {k}: {name} (rows with tiles)"
     kt = ovl.raster.kernel_times()
     assert kt["optimizer_early"] > 0 and kt["optimizer"] > 0
+
+
+def test_side_stream_optimiser_at_full_size_in_spatial_order():
+    """The bench's configuration: Morton-ordered rows, so whole 64-row waves qualify for the side stream — the waves without
+    tiles from the end of binning, the waves the forward walked nothing of from the start of the backward compositor: more than
+    5 M of the 6 M rows are updated CONCURRENTLY with the compositing kernels and the pass over the walked waves.  Every row of
+    those waves must be bit-identical to the one-pass step (parameters, both moments, activations), the rest equal up to the
+    float-atomic noise of the backward, over three steps on three views."""
+    from tests.test_gpu_native import _rows_in_unwalked_waves, exact_wave_mask
+    sc = scenes.scene_outdoor_like(n=N, seed=2)
+    ro, rd = cams.pinhole_rays(W, H, FX, FX)
+    K = cams.pinhole_intrinsics_dict(W, H, FX, FX)
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(4)).to(DEV)
+    steppers = []
+    for overlap in (False, True):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+        steppers.append(native.NativeTrainStep(model, gut.Tracer({"render": {"enable_kernel_timings": True}}), scene_extent=5.0,
+                                               overlap_optimizer=overlap))
+    ref, ovl = steppers
+    for st in steppers:   # non-zero moments everywhere, as in the bench: every row the side stream touches really changes
+        g = torch.Generator(device=DEV).manual_seed(7)
+        for m_, v_ in ((st.m12, st.v12), (st.m48, st.v48)):
+            m_.normal_(0.0, 1e-6, generator=g)
+            v_.fill_(1e-8)
+    state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48, act=st.act)
+    for k in range(3):
+        for name, t in state(ovl).items():
+            t.copy_(state(ref)[name])
+        before = {name: t.clone() for name, t in state(ref).items() if name in ("raw", "m48")}
+        c2w = cams.orbit_c2w(4.5, 7.0 + 45.0 * k, 12.0)
+        for st in (ref, ovl):
+            st.step(gut.Batch(rays_ori=torch.as_tensor(ro, device=DEV), rays_dir=torch.as_tensor(rd, device=DEV),
+                              T_to_world=torch.as_tensor(c2w)[None], rgb_gt=gt, intrinsics_OpenCVPinholeCameraModelParameters=K))
+        torch.cuda.synchronize()
+        cnt = ovl.raster.debug_buffer("tiles_count")
+        assert torch.equal(cnt, ref.raster.debug_buffer("tiles_count"))
+        exact = exact_wave_mask(cnt, _rows_in_unwalked_waves(ovl.raster, N))
+        rows = int(exact.sum())
+        assert rows > 4_500_000 and ovl.raster.stats()["side_stream_rows"] == rows
+        for name, t in state(ovl).items():
+            r = state(ref)[name]
+            assert torch.equal(r[exact], t[exact]), f"step {k}: {name} (rows of the side stream's waves)"
+            a, b = r[~exact], t[~exact]
+            if name in ("m12", "m48", "v12", "v48"):
+                tol = 1e-5 * float(a.abs().max()) + 1e-12
+                assert float((a - b).abs().max()) <= 2 * tol, f"step {k}: {name} (rows of the walked waves)"
+            else:
+                differs = (a - b).abs() > 1e-6 + 1e-5 * a.abs()
+                assert float(differs.float().mean()) < 2e-3, f"step {k}: {name}: {float(differs.float().mean())} of the elements differ"
+        # and they did move (zero-gradient Adam step on non-zero moments), i.e. the comparison above is not vacuous
+        assert float((state(ovl)["raw"][exact] - before["raw"][exact]).abs().max()) > 0
+        assert float((state(ovl)["m48"][exact] - before["m48"][exact]).abs().max()) > 0
+    kt = ovl.raster.kernel_times()
+    assert kt["optimizer_early"] > 0 and kt["optimizer_early_2"] > 0 and kt["optimizer"] > 0
