@@ -266,3 +266,49 @@ def test_side_stream_optimiser_at_full_size_in_spatial_order():
         assert float((state(ovl)["m48"][exact] - before["m48"][exact]).abs().max()) > 0
     kt = ovl.raster.kernel_times()
     assert kt["optimizer_early"] > 0 and kt["optimizer_early_2"] > 0 and kt["optimizer"] > 0
+
+
+def test_data_parallel_side_stream_at_scale():
+    """The data-parallel form of the same idea on one rank (no collectives: the choreography of torch streams, events and the
+    handle-free kernels is what is under test): gut_mark_walked_waves -> gut_adam_unwalked_waves on a side stream under the
+    backward, records + scatter + gut_sh_adam_step_ex(flags) on the main stream.  Rows of the waves the forward walked nothing
+    of must be bit-identical to the fused one-pass step, the others equal up to float-atomic noise, over three views."""
+    from tests.test_gpu_native import _rows_in_unwalked_waves
+    n = 1_500_000
+    sc = scenes.scene_outdoor_like(n=n, seed=2)
+    ro, rd = cams.pinhole_rays(W, H, FX, FX)
+    K = cams.pinhole_intrinsics_dict(W, H, FX, FX)
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(4)).to(DEV)
+    steppers = []
+    for kw in (dict(overlap_optimizer=False), dict(fuse_epilogue=False, dp_exchange="sparse", dp_side_stream=True)):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+        steppers.append(native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=5.0, **kw))
+    ref, dps = steppers
+    for st in steppers:
+        g = torch.Generator(device=DEV).manual_seed(7)
+        for m_, v_ in ((st.m12, st.v12), (st.m48, st.v48)):
+            m_.normal_(0.0, 1e-6, generator=g)
+            v_.fill_(1e-8)
+    state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48, act=st.act)
+    for k in range(3):
+        for name, t in state(dps).items():
+            t.copy_(state(ref)[name])
+        c2w = cams.orbit_c2w(4.5, 7.0 + 45.0 * k, 12.0)
+        for st in (ref, dps):
+            st.step(gut.Batch(rays_ori=torch.as_tensor(ro, device=DEV), rays_dir=torch.as_tensor(rd, device=DEV),
+                              T_to_world=torch.as_tensor(c2w)[None], rgb_gt=gt, intrinsics_OpenCVPinholeCameraModelParameters=K))
+        torch.cuda.synchronize()
+        exact = _rows_in_unwalked_waves(dps.raster, n)
+        assert torch.equal(exact, _rows_in_unwalked_waves(ref.raster, n)) and int(exact.sum()) > n // 2
+        assert torch.equal(dps.wave_flags.bool().repeat_interleave(64)[:n], ~exact)
+        assert not bool(dps.g12.any()) and not bool(dps.mrgb[0].any())
+        for name, t in state(dps).items():
+            r = state(ref)[name]
+            assert torch.equal(r[exact], t[exact]), f"step {k}: {name} (rows of waves no view walked)"
+            a, b = r[~exact], t[~exact]
+            if name in ("m12", "m48", "v12", "v48"):
+                tol = 1e-5 * float(a.abs().max()) + 1e-12
+                assert float((a - b).abs().max()) <= 2 * tol, f"step {k}: {name} (rows of the walked waves)"
+            else:
+                differs = (a - b).abs() > 1e-6 + 1e-5 * a.abs()
+                assert float(differs.float().mean()) < 2e-3, f"step {k}: {name}: {float(differs.float().mean())} of the elements differ"
