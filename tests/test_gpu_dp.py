@@ -18,8 +18,9 @@ DEV = "cuda:0"
 W, H = 80, 64
 
 
-def _views():
-    return [make_view("pinhole", W, H, cams.look_at_c2w(eye, (0, 0, 0)), fx=80) for eye in ((0.3, -0.2, -3.5), (-2.2, 0.1, -2.6))]
+def _views(world=2):
+    eyes = ((0.3, -0.2, -3.5), (-2.2, 0.1, -2.6), (1.9, 0.4, 2.4))
+    return [make_view("pinhole", W, H, cams.look_at_c2w(eye, (0, 0, 0)), fx=80) for eye in eyes[:world]]
 
 
 def _gt(k):
@@ -38,7 +39,7 @@ def _worker(rank, world, port, out_dir, fused, chunks=1, exchange="dense"):
     if fused:
         assert len(stepper.chunks) == chunks
     received = []
-    view = _views()[rank]
+    view = _views(world)[rank]
     batch = to_batch(view, DEV); batch.rgb_gt = _gt(rank)
     for _ in range(2):
         stepper.step(batch)
@@ -54,29 +55,32 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("fused,chunks,exchange", [(True, 1, "dense"), (True, 3, "dense"), (True, 1, "sparse"), (False, 1, "dense")])
-def test_two_rank_native_step_equals_mean_of_views(tmp_path, fused, chunks, exchange):
+@pytest.mark.parametrize("fused,chunks,exchange,world", [(True, 1, "dense", 2), (True, 3, "dense", 2), (True, 1, "sparse", 2),
+                                                         (True, 1, "sparse", 3), (False, 1, "dense", 2)])
+def test_multi_rank_native_step_equals_mean_of_views(tmp_path, fused, chunks, exchange, world):
     """chunks = 3: the exchange + optimiser pipeline over row chunks of the Gaussians (600 rows -> 256 + 256 + 88).
-    exchange = sparse: 64-byte records of the Gaussians each view gave a gradient to instead of dense per-view tensors."""
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), fused, chunks, exchange), nprocs=2, join=True)
-    r = [torch.load(os.path.join(tmp_path, f"r{k}.pt")) for k in range(2)]
-    assert torch.equal(r[0]["raw"], r[1]["raw"]) and torch.equal(r[0]["feats"], r[1]["feats"])  # replicas stay identical
+    exchange = sparse: 64-byte records of the Gaussians each view gave a gradient to instead of dense per-view tensors, with
+    the waves no view walked updated on a side stream (2 and 3 ranks: ragged record counts, three-way union of the wave flags)."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), fused, chunks, exchange), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"r{k}.pt")) for k in range(world)]
+    for k in range(1, world):   # replicas stay identical
+        assert torch.equal(r[0]["raw"], r[k]["raw"]) and torch.equal(r[0]["feats"], r[k]["feats"])
     if exchange == "sparse":
-        assert r[0]["clean"] and r[1]["clean"]
-        assert r[0]["received"] == r[1]["received"] and all(0 < c <= 2 * 600 for c in r[0]["received"])
+        assert all(x["clean"] for x in r)
+        assert all(x["received"] == r[0]["received"] for x in r) and all(0 < c <= world * 600 for c in r[0]["received"])
     # single-process reference: autograd path, loss = mean over the two views
     gut = importlib.import_module("3dgrut_amd"); train = importlib.import_module("3dgrut_amd.train")
     model_mod = importlib.import_module("3dgrut_amd.model"); losses = importlib.import_module("3dgrut_amd.losses")
     sc = scenes.scene_c1(600, 31)
     m = model_mod.GaussianModel(sc, device=DEV)
     opt = torch.optim.Adam(m.param_groups(1.0), eps=1e-15)
-    tracers = [gut.Tracer({"render": {}}), gut.Tracer({"render": {}})]  # one handle per in-flight view
+    tracers = [gut.Tracer({"render": {}}) for _ in range(world)]  # one handle per in-flight view
     for _ in range(2):
         loss = 0.0
-        for k, view in enumerate(_views()):
+        for k, view in enumerate(_views(world)):
             batch = to_batch(view, DEV)
             out = tracers[k].render(m, batch, train=True)
-            loss = loss + 0.5 * losses.photometric_loss(out["pred_rgb"], _gt(k))
+            loss = loss + (1.0 / world) * losses.photometric_loss(out["pred_rgb"], _gt(k))
         loss.backward()
         opt.step(); opt.zero_grad(set_to_none=True)
     raw = r[0]["raw"].numpy()
