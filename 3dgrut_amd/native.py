@@ -232,6 +232,62 @@ class NativeTrainStep:
             m.permutation = m.permutation[perm]
         self.resize_workspace()
 
+    def tune_placement(self, trials=6):
+        """Pick the best of `trials` placements of the trainer's state in HBM (call once after the model is built, and again
+        after densification / reorder, which re-allocate).  On MI355X the rate at which the optimiser streams the same 9.4 GB
+        depends on where the driver happened to put the tensors — measured inside one process on the 6 M-Gaussian bench scene:
+        5.3 TB/s for five of eight fresh allocations, 6.1 TB/s for the other three, and the whole train step follows (3.25 vs
+        3.03 ms).  Each trial times a NO-OP pass of the side-stream optimiser kernel over every row (zero learning rates,
+        beta = 1, no bias correction: it rewrites parameters, moments and activations with exactly the values they hold) and then
+        moves the state to freshly allocated memory while the earlier copies are kept alive; the fastest copy stays (the original
+        one unless another is more than 3 % faster), the others are released.  Values are untouched; transient memory is `trials` copies of the state.  Returns the trial times in ms."""
+        m = self.model
+        n = m.num_gaussians
+        if n == 0 or not m.raw.is_cuda:
+            return []
+        dev = m.raw.device
+        names = ((m, "raw"), (m, "features"), (self, "m12"), (self, "v12"), (self, "m48"), (self, "v48"), (self, "act"))
+        flags = torch.zeros(((n + 63) // 64,), dtype=torch.uint8, device=dev)
+        zero12, zero48 = (C.c_float * 12)(), (C.c_float * 48)()
+        stream = torch.cuda.current_stream(dev)
+
+        def noop_pass():
+            rc = self._lib.gut_adam_unwalked_waves(
+                C.c_void_p(stream.cuda_stream), n, flags.data_ptr(), m.raw.data_ptr(), self.m12.data_ptr(), self.v12.data_ptr(),
+                m.features.data_ptr(), self.m48.data_ptr(), self.v48.data_ptr(), zero12, zero48, 1.0, 1.0, self.eps, 0,
+                self.act.data_ptr())
+            if rc:
+                raise RuntimeError(f"[3dgut] adam_unwalked_waves failed ({rc})")
+
+        def timed(reps=3):
+            noop_pass()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                noop_pass()
+            e1.record(stream)
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        self.activate()   # the activation rows are part of what the pass rewrites: make them valid first
+        candidates, times = [], []
+        for t in range(max(1, int(trials))):
+            if t:
+                for obj, name in names:
+                    setattr(obj, name, getattr(obj, name).clone())
+            candidates.append([getattr(obj, name) for obj, name in names])
+            times.append(timed())
+        best = min(range(len(times)), key=times.__getitem__)
+        if times[0] <= 1.03 * times[best]:
+            best = 0   # the placement the state already had is as good as any seen: stay (differences below 3 % are noise)
+        for (obj, name), tensor in zip(names, candidates[best]):
+            setattr(obj, name, tensor)
+        del candidates
+        self._act_key = None
+        torch.cuda.empty_cache()
+        self.placement_trials_ms = times
+        return times
+
     def restore_spatial_order(self):
         """Re-sort the rows along the Morton curve of the CURRENT positions (after densification / pruning changed them)."""
         m = self.model

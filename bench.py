@@ -267,6 +267,8 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
             # by any of the eight views).  |m| / sqrt(v) = 0.01: the parameters drift by less than 0.1 learning-rate steps in
             # total, so the scene statistics stay what they are.
             synthetic_optimizer_state(stepper)
+        if model.num_gaussians >= 1_000_000 and not getattr(args, "no_placement_tuning", False):
+            stepper.tune_placement()   # best of six placements of the 9 GB of trainer state in HBM (NativeTrainStep.tune_placement)
     else:
         model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
         stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
@@ -366,6 +368,8 @@ def main():
     ap.add_argument("--early-extra", type=int, default=None,
                     help="GUT_OPT_EARLY_EXTRA_PERCENT (0..100): share of the row blocks in which the side stream also takes the waves "
                          "with tiles the forward walked nothing of (library default 25)")
+    ap.add_argument("--no-placement-tuning", action="store_true",
+                    help="keep the trainer state where the allocator first put it (default: NativeTrainStep.tune_placement, best of six)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
                     help="one optimiser kernel after the backward instead of the side-stream pass for the waves that cannot receive a gradient")
     args = ap.parse_args()
@@ -495,6 +499,7 @@ def main():
                        "optimizer_state": ("all-zero moments (start of training)" if (args.fresh_optimizer_state or args.trainer != "native")
                                            else "synthetic mid-training state: non-zero Adam moments on every row"),
                        "storage_order": ("morton" if (args.trainer == "native" and not args.scene_order) else "as generated"),
+                       "placement_trials_ms": [round(t, 3) for t in getattr(stepper, "placement_trials_ms", [])] or None,
                        "optimizer_overlap": bool(getattr(stepper, "overlap_optimizer", False)),
                        "optimizer_overlap_probe_ms": ({k: round(v, 3) for k, v in stepper._overlap_probe.items() if k in ("ms_on", "ms_off")}
                                                       if getattr(stepper, "_overlap_probe", None) else None)},

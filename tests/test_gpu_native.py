@@ -389,6 +389,39 @@ def test_walked_wave_flags_match_the_walked_list_prefixes():
     assert int(has_grad.sum()) > 0 and not bool((has_grad & unwalked_rows).any())
 
 
+def test_placement_tuning_moves_the_state_without_changing_it():
+    """NativeTrainStep.tune_placement: the no-op pass of the side-stream kernel (zero learning rates, beta = 1) and the moves to
+    fresh memory leave parameters, moments and activations bit-identical, and the stepper keeps training on them."""
+    sc = scenes.scene_c1(30000, 5)
+    W, H = 96, 80
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, 0.1, -3.0), (0, 0, 0)), fx=90.0)
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(6)).to(DEV)
+    steppers = []
+    for _ in range(2):
+        model = native.NativeGaussianModel(sc, device=DEV)
+        steppers.append(native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, overlap_optimizer=False))
+    ref, tuned = steppers
+    for st in steppers:
+        b = to_batch(view, DEV); b.rgb_gt = gt
+        st.step(b)                       # non-trivial moments
+    state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48)
+    before = {k: v.clone() for k, v in state(tuned).items()}
+    ptrs = {k: v.data_ptr() for k, v in state(tuned).items()}
+    act_before = tuned.activate().clone()
+    times = tuned.tune_placement(trials=4)
+    assert len(times) == 4 and all(t > 0 for t in times) and tuned.placement_trials_ms == times
+    for k, v in state(tuned).items():
+        assert torch.equal(v, before[k]), k
+    moved = any(state(tuned)[k].data_ptr() != ptrs[k] for k in ptrs)
+    assert moved == (times[0] > 1.03 * min(times))
+    assert torch.equal(tuned.activate(), act_before)
+    for st in steppers:
+        b = to_batch(view, DEV); b.rgb_gt = gt
+        st.step(b)
+    for k in before:   # (two separate runs of the backward: equal up to its float-atomic noise)
+        assert rel_l2(state(tuned)[k].cpu().numpy(), state(ref)[k].cpu().numpy()) <= 1e-4, k
+
+
 def test_half_applied_optimiser_step_is_an_error():
     sc, (_, ovl) = _native_pair(n=500)
     view = make_view("pinhole", 64, 48, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64.0)
