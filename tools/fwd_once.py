@@ -26,6 +26,7 @@ if step:
     nm = native.NativeGaussianModel(sc, device=dev, spatial_order=True)
     ts = native.NativeTrainStep(nm, tr, scene_extent=extent, overlap_optimizer=True)
     bench.synthetic_optimizer_state(ts)   # the bench's mid-training optimiser state
+    ts.tune_placement()                    # ... and its placement tuning
     b.intrinsics_OpenCVPinholeCameraModelParameters = cams.pinhole_intrinsics_dict(W, H, fx, fx)
     ro, rd, c2ws = bench.make_views(cams, 8, W, H, fx, radius, elev, False)
     b.rays_ori, b.rays_dir = torch.as_tensor(ro, device=dev), torch.as_tensor(rd, device=dev)
