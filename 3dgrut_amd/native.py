@@ -232,7 +232,7 @@ class NativeTrainStep:
             m.permutation = m.permutation[perm]
         self.resize_workspace()
 
-    def tune_placement(self, trials=6):
+    def tune_placement(self, trials=8):
         """Pick the best of `trials` placements of the trainer's state in HBM (call once after the model is built, and again
         after densification / reorder, which re-allocate).  On MI355X the rate at which the optimiser streams the same 9.4 GB
         depends on where the driver happened to put the tensors — measured inside one process on the 6 M-Gaussian bench scene:

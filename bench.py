@@ -268,7 +268,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
             # total, so the scene statistics stay what they are.
             synthetic_optimizer_state(stepper)
         if model.num_gaussians >= 1_000_000 and not getattr(args, "no_placement_tuning", False):
-            stepper.tune_placement()   # best of six placements of the 9 GB of trainer state in HBM (NativeTrainStep.tune_placement)
+            stepper.tune_placement()   # best of eight placements of the 9 GB of trainer state in HBM (NativeTrainStep.tune_placement)
     else:
         model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
         stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
@@ -369,7 +369,7 @@ def main():
                     help="GUT_OPT_EARLY_EXTRA_PERCENT (0..100): share of the row blocks in which the side stream also takes the waves "
                          "with tiles the forward walked nothing of (library default 25)")
     ap.add_argument("--no-placement-tuning", action="store_true",
-                    help="keep the trainer state where the allocator first put it (default: NativeTrainStep.tune_placement, best of six)")
+                    help="keep the trainer state where the allocator first put it (default: NativeTrainStep.tune_placement, best of eight)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
                     help="one optimiser kernel after the backward instead of the side-stream pass for the waves that cannot receive a gradient")
     args = ap.parse_args()
