@@ -270,8 +270,12 @@ class NativeTrainStep:
             return e0.elapsed_time(e1) / reps
 
         self.activate()   # the activation rows are part of what the pass rewrites: make them valid first
+        # every trial keeps its copy alive until the choice is made: no more trials than free memory holds (with a 10 % margin)
+        state_bytes = sum(getattr(obj, name).numel() * getattr(obj, name).element_size() for obj, name in names)
+        free_bytes, _ = torch.cuda.mem_get_info(dev)
+        trials = max(1, min(int(trials), 1 + int(0.9 * free_bytes) // max(1, state_bytes)))
         candidates, times = [], []
-        for t in range(max(1, int(trials))):
+        for t in range(trials):
             if t:
                 for obj, name in names:
                     setattr(obj, name, getattr(obj, name).clone())
