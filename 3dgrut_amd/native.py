@@ -178,6 +178,7 @@ class NativeTrainStep:
         self.rank = int(rank)
         self.force_exchange = os.environ.get("GUT_DP_FORCE_COLLECTIVES") == "1"  # see dp._skip
         self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
+        self.row_listeners = []         # callables(perm): told when reorder() re-sorts the rows (strategy statistics follow)
         self.resize_workspace()
         self.step_id = 0
         self.phase_timing = False   # record HIP events around the phases of step() (bench / profiling)
@@ -230,6 +231,8 @@ class NativeTrainStep:
         self.m48, self.v48 = self.m48[perm].contiguous(), self.v48[perm].contiguous()
         if m.permutation is not None:
             m.permutation = m.permutation[perm]
+        for fn in self.row_listeners:
+            fn(perm)
         self.resize_workspace()
 
     def tune_placement(self, trials=8):

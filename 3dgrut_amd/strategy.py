@@ -65,6 +65,9 @@ class _StateOps:
 
     def keep(self, mask):
         self._apply(lambda p: p[mask].contiguous(), lambda v: v[mask].contiguous())
+        perm = getattr(self.m, "permutation", None)
+        if perm is not None:   # stored row i came from row permutation[i] of the scene as given; rows added later get -1
+            self.m.permutation = perm[mask.to(perm.device)]
 
     def append(self, raw_new, feat_new):
         s, m = self.s, self.m
@@ -73,18 +76,82 @@ class _StateOps:
         m.features = torch.cat([m.features, feat_new]).contiguous()
         z = lambda v: torch.cat([v, torch.zeros((k, v.shape[1]), dtype=v.dtype, device=v.device)]).contiguous()
         s.m12, s.v12, s.m48, s.v48 = z(s.m12), z(s.v12), z(s.m48), z(s.v48)
+        perm = getattr(m, "permutation", None)
+        if perm is not None:
+            m.permutation = torch.cat([perm, torch.full((k,), -1, dtype=perm.dtype, device=perm.device)])
         s.resize_workspace()
 
 
+# configs/strategy/gs.yaml: (start_iteration, end_iteration, frequency) of each operation; -1 start = never
+GS_SCHEDULE = dict(densify=(500, 15000, 300), prune=(500, 15000, 100), reset_density=(0, 15000, 3000), density_decay=(-1, -1, 50))
+
+
 class GSStrategy:
+    """threedgrut/strategy/gs.py:26-306 on the native layout.  Defaults are configs/strategy/gs.yaml's.
+
+    Live use with a NativeTrainStep (what trainer.py:741-760 does with its strategy object):
+        gs = GSStrategy(stepper); gs.attach()          # per-view statistics hook + row bookkeeping
+        for step ...: stepper.step(batch); gs.post_optimizer_step(step, scene_extent)
+    attach() makes the stepper hand this view's position gradient to update_gradient_buffer after every backward
+    (post_backward, gs.py:60-73) and keeps the statistics rows aligned when the stepper re-sorts its rows."""
+
     def __init__(self, stepper, clone_grad_threshold=0.0002, split_grad_threshold=0.0002, relative_size_threshold=0.01,
-                 split_n_gaussians=2, prune_density_threshold=0.005, new_max_density=0.01, density_decay_gamma=0.995, seed=0):
+                 split_n_gaussians=2, prune_density_threshold=0.005, new_max_density=0.01, density_decay_gamma=0.99, seed=0,
+                 schedule=None):
         self.ops = _StateOps(stepper)
         self.clone_thr, self.split_thr = clone_grad_threshold, split_grad_threshold
         self.rel_size, self.split_n = relative_size_threshold, split_n_gaussians
         self.prune_thr, self.new_max_density, self.decay_gamma = prune_density_threshold, new_max_density, density_decay_gamma
         self.seed = seed
+        self.schedule = dict(GS_SCHEDULE if schedule is None else schedule)
+        # split(): standard-normal draws [k * split_n, 3] for the children's offsets; None = a generator seeded with
+        # (seed, step), identical on every data-parallel rank.  (The reference draws torch.normal on the CUDA generator, gs.py:145.)
+        self.unit_normal_fn = None
         self.reset_buffers()
+
+    # ---- trainer callbacks (gs.py:60-104) ----
+    def attach(self):
+        s = self.ops.s
+        s.post_backward_hook = self._post_backward
+        listeners = getattr(s, "row_listeners", None)
+        if listeners is not None and self._rows_reordered not in listeners:
+            listeners.append(self._rows_reordered)
+        return self
+
+    def detach(self):
+        s = self.ops.s
+        if getattr(s, "post_backward_hook", None) == self._post_backward:
+            s.post_backward_hook = None
+
+    def _post_backward(self, position_grad, sensor_position):
+        """gs.py:60-66: the buffer is updated for 0 < step < densify.end_iteration."""
+        from .schedule import check_step_condition
+        if check_step_condition(int(getattr(self.ops.s, "step_id", 1)), 0, self.schedule["densify"][1], 1):
+            self.update_gradient_buffer(position_grad, sensor_position)
+
+    def _rows_reordered(self, perm):
+        perm = perm.to(self.grad_norm_accum.device)
+        self.grad_norm_accum, self.grad_norm_denom = self.grad_norm_accum[perm], self.grad_norm_denom[perm]
+
+    def post_optimizer_step(self, step, scene_extent, world=1):
+        """gs.py:75-104 with utils/misc.check_step_condition.  Returns True when the number or order of rows changed."""
+        from .schedule import check_step_condition
+        sc, updated = self.schedule, False
+        if check_step_condition(step, *sc["densify"]):
+            self.densify(scene_extent, step, world)
+            updated = True
+        if check_step_condition(step, *sc["prune"]):
+            self.prune_opacity()
+            updated = True
+        if check_step_condition(step, *sc["density_decay"]):
+            self.decay_density()
+        if check_step_condition(step, *sc["reset_density"]):
+            self.reset_density()
+        if step >= sc["densify"][1]:
+            self.detach()   # update_gradient_buffer only runs up to densify.end_iteration (gs.py:64)
+        if updated and getattr(self.ops.m, "spatial_order", False):
+            self.ops.s.restore_spatial_order()
+        return updated
 
     def reset_buffers(self):
         dev = self.ops.m.raw.device
@@ -130,9 +197,13 @@ class GSStrategy:
         mask = (padded >= self.split_thr) & (scale.max(dim=1).values > self.rel_size * scene_extent)
         k = int(mask.sum())
         if k:
-            gen = torch.Generator(device=m.raw.device).manual_seed(self.seed * 1_000_003 + step)
             stds = scale[mask].repeat(self.split_n, 1)
-            samples = torch.randn(stds.shape, generator=gen, device=stds.device) * stds
+            if self.unit_normal_fn is not None:
+                unit = self.unit_normal_fn(stds.shape).to(stds.device)
+            else:
+                gen = torch.Generator(device=m.raw.device).manual_seed(self.seed * 1_000_003 + step)
+                unit = torch.randn(stds.shape, generator=gen, device=stds.device)
+            samples = unit * stds
             rots = _quat_to_rotmat(m.raw[:, ROT][mask]).repeat(self.split_n, 1, 1)
             offsets = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1)
             raw_new = m.raw[mask].repeat(self.split_n, 1)
@@ -153,8 +224,8 @@ class GSStrategy:
 
     @torch.no_grad()
     def decay_density(self):
-        d = torch.sigmoid(self.ops.m.raw[:, 3]) * self.decay_gamma
-        self.ops.m.raw[:, 3] = torch.log(d / (1 - d))
+        d = torch.sigmoid(self.ops.m.raw[:, 3:4].contiguous()) * self.decay_gamma   # contiguous [N,1], as the reference's parameter
+        self.ops.m.raw[:, 3:4] = torch.log(d / (1 - d))
 
     @torch.no_grad()
     def reset_density(self):

@@ -328,3 +328,92 @@ def test_train_schedule_follows_the_reference_iteration_order(G):
             assert abs(lr - ref[g]) <= 1e-12 * ref[g]
         degs[g] = deg
     assert degs[999] == 0 and degs[1000] == 1 and degs[1999] == 1 and degs[2000] == 2 and degs[3000] == 3 and degs[4001] == 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N3: strategy.GSStrategy against threedgrut/strategy/gs.py itself (tests/golden/gen_strategy_golden.py drove the
+# reference's GSStrategy + BaseStrategy._update_param_with_optimizer on a fake MixtureOfGaussians with a real
+# torch.optim.Adam; strategy_golden.npz holds every parameter, both Adam moments and the densification buffers after each
+# stage).  Same inputs, same recorded standard-normal draws for the split -> same rows, in the same order.
+# ---------------------------------------------------------------------------------------------------------------------
+_REF_PARAMS = ("positions", "density", "rotation", "scale", "features_albedo", "features_specular")
+
+
+class _StrategyStepper:
+    """NativeTrainStep's state as strategy.py sees it (tensors only; no GPU)."""
+    def __init__(self, S, tag):
+        native = importlib.import_module("3dgrut_amd.native")
+        t = lambda k: torch.as_tensor(S[f"{tag}/{k}"])
+        n = S[f"{tag}/positions"].shape[0]
+        self.model = native.NativeGaussianModel.__new__(native.NativeGaussianModel)
+        self.model.raw, self.m12, self.v12 = (torch.zeros(n, 12) for _ in range(3))
+        for dst, suffix in ((self.model.raw, ""), (self.m12, "/exp_avg"), (self.v12, "/exp_avg_sq")):
+            dst[:, 0:3], dst[:, 3:4], dst[:, 4:8], dst[:, 8:11] = (t(k + suffix) for k in ("positions", "density", "rotation", "scale"))
+        cat = lambda suffix: torch.cat([t("features_albedo" + suffix), t("features_specular" + suffix)], 1).contiguous()
+        self.model.features, self.m48, self.v48 = cat(""), cat("/exp_avg"), cat("/exp_avg_sq")
+        self.model.permutation, self.model.spatial_order = None, False
+        self.row_listeners, self.post_backward_hook, self.step_id = [], None, 1
+
+    def resize_workspace(self):
+        pass
+
+
+def _assert_stage(S, tag, st, gs, exact=True, skip=()):
+    cmp_ = (lambda a, b, what: np.testing.assert_array_equal(a, b, err_msg=what)) if exact else \
+        (lambda a, b, what: np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7, err_msg=what))
+    for src, suffix in ((st.model.raw, ""), (st.m12, "/exp_avg"), (st.v12, "/exp_avg_sq")):
+        for k, sl in (("positions", slice(0, 3)), ("density", slice(3, 4)), ("rotation", slice(4, 8)), ("scale", slice(8, 11))):
+            if (k + suffix) not in skip:
+                cmp_(src[:, sl].numpy(), S[f"{tag}/{k}{suffix}"], f"{tag}/{k}{suffix}")
+    for src, suffix in ((st.model.features, ""), (st.m48, "/exp_avg"), (st.v48, "/exp_avg_sq")):
+        cmp_(src[:, 0:3].numpy(), S[f"{tag}/features_albedo{suffix}"], f"{tag}/features_albedo{suffix}")
+        cmp_(src[:, 3:].numpy(), S[f"{tag}/features_specular{suffix}"], f"{tag}/features_specular{suffix}")
+    np.testing.assert_allclose(gs.grad_norm_accum.numpy(), S[f"{tag}/grad_norm_accum"], rtol=2e-6, atol=1e-12, err_msg=f"{tag}/accum")
+    np.testing.assert_array_equal(gs.grad_norm_denom.numpy(), S[f"{tag}/grad_norm_denom"], err_msg=f"{tag}/denom")
+
+
+def test_gs_strategy_against_the_reference():
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    S = np.load(os.path.join(GOLD, "strategy_golden.npz"))
+    st = _StrategyStepper(S, "start")
+    gs = strategy.GSStrategy(st, seed=0).attach()
+    assert st.post_backward_hook is not None
+    extent = float(S["scene_extent"])
+    # post_backward x 3 views (gs.py:106-115)
+    for g, s in zip(S["view_grads"], S["view_sensors"]):
+        st.post_backward_hook(torch.as_tensor(g), torch.as_tensor(s))
+    _assert_stage(S, "after_buffer", st, gs)
+    # densify_gaussians = clone then split (gs.py:117-210) with the recorded draws
+    unit, used = torch.as_tensor(S["unit_draws"]), []
+    def draws(shape):
+        used.append(shape[0])
+        return unit[sum(used[:-1]):sum(used)]
+    gs.unit_normal_fn = draws
+    n0 = st.model.raw.shape[0]
+    gs.densify(extent, step=600)
+    assert sum(used) == int(S["draws_used"]) and st.model.raw.shape[0] == S["after_densify/positions"].shape[0] > n0
+    # every row and both moments bit for bit, except the split children's positions: R(q) @ (unit * std) is evaluated with
+    # torch.nn.functional.normalize here and with the reference's own quaternion_to_so3 there (last-ulp differences)
+    _assert_stage(S, "after_densify", st, gs, skip=("positions",))
+    np.testing.assert_allclose(st.model.raw[:, 0:3].numpy(), S["after_densify/positions"], rtol=1e-5, atol=2e-7)
+    st.model.raw[:, 0:3] = torch.as_tensor(S["after_densify/positions"])     # continue from the reference's bits
+    assert gs.prune_opacity() == S["after_densify/positions"].shape[0] - S["after_prune/positions"].shape[0] > 0
+    _assert_stage(S, "after_prune", st, gs)
+    gs.decay_density()
+    _assert_stage(S, "after_decay", st, gs)
+    gs.reset_density()
+    _assert_stage(S, "after_reset", st, gs, exact=False)    # the clamp bound is logit(0.01) in float32 there, in double here
+    assert float(st.m12[:, 3].abs().max()) == 0.0 and float(st.v12[:, 3].abs().max()) == 0.0
+
+
+def test_gs_schedule_against_the_reference():
+    """post_optimizer_step / post_backward fire on exactly the iterations the reference's check_step_condition selects for
+    configs/strategy/gs.yaml (fixture: the selected iterations 0..16000)."""
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    S = np.load(os.path.join(GOLD, "strategy_golden.npz"))
+    sc = strategy.GS_SCHEDULE
+    for key, name in (("schedule_densify", "densify"), ("schedule_prune", "prune"), ("schedule_reset", "reset_density")):
+        mine = [s for s in range(16001) if schedule.check_step_condition(s, *sc[name])]
+        assert mine == S[key].tolist(), name
+    assert [s for s in range(20) if schedule.check_step_condition(s, 0, sc["densify"][1], 1)] == S["schedule_buffer"].tolist()
+    assert not any(schedule.check_step_condition(s, *sc["density_decay"]) for s in range(16001))

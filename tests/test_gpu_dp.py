@@ -90,3 +90,127 @@ def test_multi_rank_native_step_equals_mean_of_views(tmp_path, fused, chunks, ex
     assert rel_l2(raw[:, 8:11], m.scale.detach().cpu().numpy()) <= 1e-4
     feats = torch.cat([m.features_albedo, m.features_specular], 1).detach().cpu().numpy()
     assert rel_l2(r[0]["feats"].numpy(), feats) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] on ITS workload (bench.WORKLOADS["garden_like_5M_1297x840"]): two ranks, one view each (views 0
+# and 1 of the bench), full N = 5 M, rows in the trainer's Morton order — two processes share cuda:0 and exchange over gloo.
+# Both exchange forms (sparse records + side stream; dense compact, 4 row chunks) in one spawn, each checked by rank 0
+# against ONE single-process reference: the autograd path (Tracer.render -> torch loss -> backward -> torch.optim.Adam) on
+# the mean loss of the same two views.
+# ---------------------------------------------------------------------------------------------------------------------
+GARDEN = "garden_like_5M_1297x840"
+
+
+def _checksum(t):
+    """Order-sensitive 2 x 64-bit checksum of a tensor's bits (replica identity without shipping 1.2 GB per rank)."""
+    x = t.detach().contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+    w = (torch.arange(x.numel(), device=x.device, dtype=torch.int64) % 65521) + 1
+    return int(x.sum().item()), int((x * w).sum().item())
+
+
+def _garden_inputs():
+    import bench
+    fn, kw, W_, H_, fx, radius, elev, extent = bench.WORKLOADS[GARDEN]
+    sc = getattr(scenes, fn)(**kw)
+    views = [make_view("pinhole", W_, H_, cams.orbit_c2w(radius, 360.0 * i / 8 + 7.0, elev), fx=fx, fy=fx) for i in range(2)]  # bench.make_views
+    gts = [torch.rand((1, H_, W_, 3), generator=torch.Generator().manual_seed(40 + k)) for k in range(2)]
+    return sc, views, gts, extent
+
+
+def _garden_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gut = importlib.import_module("3dgrut_amd"); native = importlib.import_module("3dgrut_amd.native")
+    from tests.common import check_gradient_rows, GRAD_BLOCKS
+    torch.cuda.set_device(0)
+    sc, views, gts, extent = _garden_inputs()
+    n = sc["positions"].shape[0]
+    batch = to_batch(views[rank], DEV); batch.T_to_world = batch.T_to_world.cpu(); batch.rgb_gt = gts[rank].to(DEV)
+    results = {}
+    perm = None
+    for exchange in ("sparse", "dense"):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+        stepper = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=extent, world_size=world, rank=rank,
+                                         dp_exchange=exchange)
+        assert stepper.dp_exchange == exchange and (exchange == "sparse" or len(stepper.chunks) == 4)
+        perm = model.permutation.cpu().numpy()
+        raw0 = model.raw.clone()
+        stepper.step(batch)
+        torch.cuda.synchronize()
+        m12_1, m48_1 = stepper.m12.clone(), stepper.m48.clone()
+        received = getattr(stepper, "exchanged_records", -1)
+        stepper.step(batch)
+        torch.cuda.synchronize()
+        sums = {k: _checksum(t) for k, t in dict(raw=model.raw, feats=model.features, m12=stepper.m12, v12=stepper.v12, m48=stepper.m48,
+                                                 v48=stepper.v48).items()}
+        clean = True
+        if exchange == "sparse":
+            clean = not bool(stepper.g12.any()) and not bool(stepper.mrgb[0].any())
+        results[exchange] = dict(sums=sums, received=received, clean=clean)
+        if rank == 0:
+            results[exchange].update(m12_1=m12_1, m48_1=m48_1, raw=model.raw.clone(), feats=model.features.clone(), raw0=raw0)
+        del stepper, model
+        torch.cuda.empty_cache()
+    torch.save({k: dict(sums=v["sums"], received=v["received"], clean=v["clean"]) for k, v in results.items()}, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier(); dist.destroy_process_group()
+    if rank != 0:
+        return
+    # ---- single-process reference (this process alone now): autograd path, loss = mean over the two views, same row order ----
+    train = importlib.import_module("3dgrut_amd.train"); model_mod = importlib.import_module("3dgrut_amd.model")
+    losses = importlib.import_module("3dgrut_amd.losses")
+    m = model_mod.GaussianModel({k: np.asarray(v)[perm] for k, v in sc.items()}, device=DEV)
+    opt = torch.optim.Adam(m.param_groups(extent), eps=1e-15)
+    tracers = [gut.Tracer({"render": {}}) for _ in range(world)]
+    report = {}
+    for it in range(2):
+        loss = 0.0
+        for k in range(world):
+            b = to_batch(views[k], DEV)
+            out = tracers[k].render(m, b, train=True)
+            loss = loss + (1.0 / world) * losses.photometric_loss(out["pred_rgb"], gts[k].to(DEV))
+        loss.backward()
+        opt.step(); opt.zero_grad(set_to_none=True)
+        if it == 0:
+            # first moments after step 1 = 0.1 x the mean gradient over the two views: a per-row gradient comparison
+            ea = lambda p: opt.state[p]["exp_avg"].detach().cpu().numpy()
+            ref12 = np.concatenate([ea(m.positions), ea(m.density), ea(m.rotation), ea(m.scale)], 1)
+            ref48 = np.concatenate([ea(m.features_albedo), ea(m.features_specular)], 1)
+            for exchange, r in results.items():
+                got12 = r["m12_1"].cpu().numpy()
+                for name, sl in GRAD_BLOCKS:
+                    report[f"{exchange}/m/{name}"] = check_gradient_rows(got12[:, sl], ref12[:, sl], f"garden dp2 {exchange} m/{name}")
+                report[f"{exchange}/m/sh"] = check_gradient_rows(r["m48_1"].cpu().numpy(), ref48, f"garden dp2 {exchange} m/sh")
+    ref_raw = torch.cat([m.positions, m.density, m.rotation, m.scale], 1).detach()
+    ref_feats = torch.cat([m.features_albedo, m.features_specular], 1).detach()
+    for exchange, r in results.items():
+        raw, raw0 = r["raw"][:, :11], r["raw0"][:, :11]
+        for name, sl in GRAD_BLOCKS:
+            assert rel_l2(raw[:, sl].cpu().numpy(), ref_raw[:, sl].cpu().numpy()) <= 1e-4, (exchange, name)
+        assert rel_l2(r["feats"].cpu().numpy(), ref_feats.cpu().numpy()) <= 1e-4, exchange
+        # the UPDATE of two steps (parameters minus their start), element by element: Adam's step is ~ lr * sign(g) while the
+        # second moment is young, so an element whose gradient is pure float-atomic noise may differ by up to 2 lr; a wrong
+        # exchange (a view's records dropped, a chunk scattered to the wrong rows) would differ on every row the views touched
+        moved = ((ref_raw - raw0).abs() > 0).any(1)
+        assert int(moved.sum()) > 100_000
+        differs = ((raw - ref_raw).abs() > 1e-6 + 1e-5 * ref_raw.abs())[moved]
+        frac = float(differs.float().mean())
+        upd = rel_l2((raw - raw0)[moved].cpu().numpy(), (ref_raw - raw0)[moved].cpu().numpy())
+        print(f"[garden dp2 {exchange}] rows moved {int(moved.sum())}, elements differing {frac:.2e}, update rel-L2 {upd:.2e}")
+        assert frac <= 5e-3 and upd <= 5e-2, (exchange, frac, upd)
+    s_, d_ = results["sparse"], results["dense"]
+    assert rel_l2(s_["raw"].cpu().numpy(), d_["raw"].cpu().numpy()) <= 1e-6   # the two exchange forms carry the same sums
+
+
+def test_garden_workload_two_rank_step_at_full_size(tmp_path):
+    """configs[4] (garden-like 5 M Gaussians, 1297x840, one view per rank) as a 2-rank data-parallel step, sparse AND dense
+    exchange, replicas bit-identical and equal to the single-process step on the mean loss of the two views (per-row on the
+    first moments, i.e. on the exchanged gradients; parameters after two steps)."""
+    world = 2
+    mp.spawn(_garden_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"g{k}.pt")) for k in range(world)]
+    for exchange in ("sparse", "dense"):
+        assert r[0][exchange]["sums"] == r[1][exchange]["sums"], f"{exchange}: replicas differ"
+        assert r[0][exchange]["clean"] and r[1][exchange]["clean"]
+    rec = r[0]["sparse"]["received"]
+    assert rec == r[1]["sparse"]["received"] and 100_000 < rec < 2 * 5_000_000

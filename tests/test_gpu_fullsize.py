@@ -15,7 +15,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import cams, check_colour_outliers, rel_l2, scenes
+from tests.common import (cams, check_colour_outliers, check_gradients_per_row, check_side_stream_rows_are_gradient_free, rel_l2,
+                          scenes)
 
 pytestmark = pytest.mark.gpu
 gut = importlib.import_module("3dgrut_amd")
@@ -28,7 +29,7 @@ N, W, H, FX = 6_000_000, 1237, 822, 1040.0
 @pytest.fixture(scope="module")
 def frame():
     sc = scenes.scene_outdoor_like(n=N, seed=2)
-    model = native.NativeGaussianModel(sc, device=DEV)
+    model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)   # the bench's storage order (Morton)
     tracer = gut.Tracer({"render": {}})
     stepper = native.NativeTrainStep(model, tracer, scene_extent=5.0)
     ro, rd = cams.pinhole_rays(W, H, FX, FX)
@@ -166,6 +167,13 @@ def test_full_size_frame_against_the_oracle(frame):
         assert rel_l2(g12[:, sl], dens_g[:, sl]) <= 2e-3, name
     assert rel_l2(g48, sph_g) <= 2e-3
     assert frame["stats"]["num_intersections"] == ref["M"] and frame["raster"].stats()["traversed_bwd"] == ref["traversed_bwd"]
+    # ... and per ROW (a block-wide L2 over 6 M rows would hide a few thousand wrong small rows)
+    check_gradients_per_row(g12, g48, dens_g, sph_g, "bicycle_like_6M")
+    # the waves the side-stream optimiser pass takes from this frame: the oracle — which ends its rays by its own rule — and the
+    # GPU both leave every one of their rows without a gradient, exactly
+    from tests.test_gpu_native import _rows_in_unwalked_waves, exact_wave_mask
+    owned = exact_wave_mask(frame["raster"].debug_buffer("tiles_count"), _rows_in_unwalked_waves(frame["raster"], N)).cpu().numpy()
+    check_side_stream_rows_are_gradient_free(owned, g12, g48, dens_g, sph_g, "bicycle_like_6M", min_rows=4_500_000)
 
 
 def test_two_pass_optimiser_at_full_size_with_finely_interleaved_rows():
