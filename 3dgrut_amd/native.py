@@ -78,6 +78,19 @@ class NativeGaussianModel:
         self.background_color = background_color
         self.device = device
 
+    @classmethod
+    def from_tensors(cls, raw, features, sh_degree=3, background_color="black", spatial_order=False, permutation=None):
+        """A model around existing parameter tensors: raw [N,12] (pos3, density logit, quat4, log-scale3, unused) and features
+        [N,48], stored as they are (checkpoint resume, or a second trainer on a copy of a live state)."""
+        m = cls.__new__(cls)
+        if raw.dim() != 2 or raw.shape[1] != 12 or features.shape != (raw.shape[0], 48):
+            raise ValueError("from_tensors: raw must be [N,12] and features [N,48]")
+        m.raw, m.features = raw.contiguous(), features.contiguous()
+        m.spatial_order, m.permutation = bool(spatial_order), permutation
+        m.n_active_features, m.max_n_features = int(sh_degree), 3
+        m.background_color, m.device = background_color, raw.device
+        return m
+
     @property
     def num_gaussians(self):
         return self.raw.shape[0]

@@ -979,13 +979,29 @@ static void matmul_bw_quat(const float p[3], const float g[3], const float q[4],
  * rayPayloadBackward.cuh:30-58.  Per-pair math in fp32 exactly as the reference; the cross-pixel
  * sums (float atomics in the reference, order undefined) are taken in double here.
  * Quirk 1: integratedDepth == 0 so residualHitT == 0.
- * density_grad [N,12] (pos3, density, quat4 wxyz, scale3, pad) and feat_grad [N,3], both doubles. */
-void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+ * density_grad [N,12] (pos3, density, quat4 wxyz, scale3, pad) and feat_grad [N,3], both doubles.
+ *
+ * flip_budget (tests only, may be NULL): [N,10] doubles; columns 0..4 (positions, density, rotation, scale, colour) receive, per Gaussian,
+ * how far a DIFFERENT BUT EQUALLY VALID fp32 evaluation of the same formulas may move that row of the gradient because a
+ * hit / no-hit decision flips: the reference's per-hit gradient is discontinuous at the min_response and min_alpha
+ * thresholds (a hit with alpha ~ 1/255 on a faint Gaussian has d alpha / d sigma = response ~ 1: the density row jumps).
+ * A decision counts as flip-prone when its margin (the same noise model as oracle_render_margins) is below flip_bound:
+ *   - the prone entry's own row may gain or lose its whole contribution from that pixel  -> += |contribution| (evaluated
+ *     as if accepted, whether this evaluation accepted it or not);
+ *   - every other entry the ray walks sees T, the final T and the final colour change by the flipped hit's alpha (<= 0.0113,
+ *     or 1/255 / (1 - 1/255)): its contribution moves by that share -> += 4 x sum(alpha_f / (1 - alpha_f)) x |contribution|.
+ * Rows that get no budget have no flip-prone decision on any ray that touches them.
+ * Columns 5..9 of the [N,10] array: the fp32 conditioning of each row, sum over its hits of eps x nu x |contribution| with
+ * nu the response's noise estimate of oracle_render_margins (the response is exp(-|grd x gro|^2 / 2) with |gro| = the
+ * camera distance in units of the Gaussian's size: a relative error of eps x nu, up to 1e-3 for a small, distant Gaussian,
+ * which every term of the hit's gradient inherits; the geometric rows additionally 8 eps |gro|, see below) — what ANY fp32
+ * evaluation order may differ by on that row. */
+static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, int W, int H,
                        const float* density12, const float* feat,
                        const float* ray_ori, const float* ray_dir,
                        const uint32_t* ranges, const uint32_t* sorted_ids,
                        const float* rgba, const float* rgba_grad, const float* dist, const float* dist_grad,
-                       double* density_grad, double* feat_grad, uint64_t* traversed_out) {
+                       double* density_grad, double* feat_grad, uint64_t* traversed_out, double* flip_budget, float flip_bound) {
     const PoseSet ps = make_pose_set(cam);
     const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
     uint64_t traversed_total = 0;
@@ -1007,9 +1023,38 @@ void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, 
                 const float rgb_final[3] = {rgba[4 * pix], rgba[4 * pix + 1], rgba[4 * pix + 2]};
                 const float rgb_g[3] = {rgba_grad[4 * pix], rgba_grad[4 * pix + 1], rgba_grad[4 * pix + 2]};
                 const float depth_g = dist_grad[pix];
+                /* flip budget, first pass over the ray: the summed alpha share of its flip-prone decisions */
+                float taint = 0.0f;
+                if (flip_budget) {
+                    float Tp = 1.0f;
+                    for (uint32_t kk = beg; kk < end; ++kk) {
+                        const uint32_t id = sorted_ids[kk];
+                        if (id == INVALID_IDX) break;
+                        const float* g = density12 + (size_t)id * 12;
+                        float rows[3][3];
+                        quat_to_rows(g + 4, rows);
+                        Hit h;
+                        eval_hit(prm, g, rows, &ray, &h);
+                        const float gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
+                        const float nu = sqrtf(h.d2) * gn + 0.5f * h.d2 + 2.0f, eps = 5.9604645e-08f;
+                        int prone = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu) < flip_bound;
+                        if (h.resp > prm->min_kernel_density)
+                            prone |= fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu) < flip_bound;
+                        if (prone) taint += h.alpha / (1.0f - h.alpha);
+                        if ((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold)) {
+                            Tp *= (1.0f - h.alpha);
+                            if (Tp < prm->min_transmittance) break;
+                        }
+                    }
+                }
                 float T = 1.0f, rgb_run[3] = {0, 0, 0};
-                uint32_t k = beg;
-                for (; k < end && ray.alive; ++k) {
+                /* flip budget: once the running transmittance has come within flip_bound noise widths of min_transmittance the
+                 * ray may end one entry earlier or later in another evaluation: from there on every entry's contribution is
+                 * budgeted whole, and a ray that ended there is walked on ("ghost") for the budget alone until T < Tmin / 4 */
+                float t_noise = 1.0f;
+                int term_prone = 0, ghost = 0;
+                uint32_t k = beg, k_end = 0;
+                for (; k < end && (ray.alive || ghost); ++k) {
                     const uint32_t id = sorted_ids[k];
                     if (id == INVALID_IDX) break;
                     const float* g = density12 + (size_t)id * 12;
@@ -1018,7 +1063,18 @@ void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, 
                     quat_to_rows(q, rows);
                     Hit h;
                     eval_hit(prm, g, rows, &ray, &h);
-                    if (!((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold))) continue;
+                    const int accept = (h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold);
+                    int prone = 0;
+                    float nu = 0.0f, gn = 0.0f;
+                    if (flip_budget) {
+                        gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
+                        const float eps = 5.9604645e-08f;
+                        nu = sqrtf(h.d2) * gn + 0.5f * h.d2 + 2.0f;
+                        prone = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu) < flip_bound;
+                        if (h.resp > prm->min_kernel_density)
+                            prone |= fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu) < flip_bound;
+                    }
+                    if (!accept && !prone) continue;
                     /* NB: no tmin/tmax test in the backward (gaussianParticles.cuh:530) */
                     const float proj = h.grd[0] * -h.gro[0] + h.grd[1] * -h.gro[1] + h.grd[2] * -h.gro[2];
                     const float grdd[3] = {h.grd[0] * proj, h.grd[1] * proj, h.grd[2] * proj};
@@ -1041,14 +1097,13 @@ void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, 
                                                -s[2] * h.grd[2] * h.grd[2] * g_grds[2]};
                     const float res_T = h.alpha < 0.999999f ? T_final / (1.0f - h.alpha) : T;
                     const float ga_dns = res_T * -T_grad;
-                    float f[3], res_rad[3];
+                    float f[3], res_rad[3], run_after[3], feat_add[3];
                     for (int c = 0; c < 3; ++c) {
                         const float fv = feat[3 * (size_t)id + c];
                         f[c] = fv > 0.0f ? fv : 0.0f;
-#pragma omp atomic
-                        feat_grad[3 * (size_t)id + c] += (double)(rgb_g[c] * w);
-                        rgb_run[c] += w * f[c];
-                        const float rr = (Tn <= prm->min_transmittance) ? 0.0f : (rgb_final[c] - rgb_run[c]) / Tn;
+                        feat_add[c] = rgb_g[c] * w;
+                        run_after[c] = rgb_run[c] + w * f[c];
+                        const float rr = (Tn <= prm->min_transmittance) ? 0.0f : (rgb_final[c] - run_after[c]) / Tn;
                         res_rad[c] = rr > 0.0f ? rr : 0.0f;
                     }
                     const float G = ga_hit + ga_dns + T * (f[0] - res_rad[0]) * rgb_g[0] + T * (f[1] - res_rad[1]) * rgb_g[1] +
@@ -1093,21 +1148,95 @@ void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, 
                     }
                     float q_b[4];
                     matmul_bw_quat(ray.d, g_rdr, q, q_b);
-                    double* dg = density_grad + 12 * (size_t)id;
                     const double add[11] = {-g_gposc[0], -g_gposc[1], -g_gposc[2], d_sigma, q_a[0] + q_b[0], q_a[1] + q_b[1],
                                             q_a[2] + q_b[2], q_a[3] + q_b[3], d_scale[0], d_scale[1], d_scale[2]};
-                    for (int c = 0; c < 11; ++c) {
+                    if (flip_budget) {
+                        /* every geometric term of the hit's gradient is proportional to G, a SUM of terms of either sign (final
+                         * transmittance, colour residuals): what moves G is measured against the sum of their magnitudes */
+                        const double G_abs = fabs((double)ga_hit) + fabs((double)ga_dns) +
+                                             (double)T * ((fabs((double)f[0]) + res_rad[0]) * fabs((double)rgb_g[0]) +
+                                                          (fabs((double)f[1]) + res_rad[1]) * fabs((double)rgb_g[1]) +
+                                                          (fabs((double)f[2]) + res_rad[2]) * fabs((double)rgb_g[2]));
+                        double cond = G_abs / fmax(fabs((double)G), 1e-30 + 1e-3 * G_abs);   /* >= 1, capped at 1e3 */
+                        if (!(cond >= 1.0)) cond = 1.0;
+                        if (term_prone) prone = 1;
+                        const double share = prone ? 1.0 : 4.0 * (double)taint;
+                        const double noise = (accept && !ghost) ? 5.9604645e-08 * ((double)nu + 8.0 * cond) : 0.0;
+                        const double nb[5] = {sqrt(add[0] * add[0] + add[1] * add[1] + add[2] * add[2]), fabs(add[3]),
+                                              sqrt(add[4] * add[4] + add[5] * add[5] + add[6] * add[6] + add[7] * add[7]),
+                                              sqrt(add[8] * add[8] + add[9] * add[9] + add[10] * add[10]),
+                                              sqrt((double)feat_add[0] * feat_add[0] + (double)feat_add[1] * feat_add[1] +
+                                                   (double)feat_add[2] * feat_add[2])};
+                        for (int c = 0; c < 5; ++c) {
+                            if (share > 0.0) {
+                                /* a flipped hit elsewhere on the ray moves the terms of G by its alpha share (colour block: w only) */
+                                const double sh = (prone || c == 4) ? share : share * cond;
 #pragma omp atomic
-                        dg[c] += add[c];
+                                flip_budget[10 * (size_t)id + c] += sh * nb[c];
+                            }
+                            if (noise > 0.0) {
+                                /* positions / rotation / scale: the ray's offset from the Gaussian in units of its size, gro, of
+                                 * magnitude gn (1e4 for a sub-pixel Gaussian a few units away), enters through its component
+                                 * perpendicular to the ray, of magnitude d ~ 1: a cancellation that leaves eps x gn there */
+                                const double nz_ = (c == 0 || c == 2 || c == 3) ? noise + 5.9604645e-08 * 8.0 * (double)gn : noise;
+#pragma omp atomic
+                                flip_budget[10 * (size_t)id + 5 + c] += nz_ * nb[c];
+                            }
+                        }
                     }
+                    if (!accept) continue;
+                    if (!ghost) {
+                        double* dg = density_grad + 12 * (size_t)id;
+                        for (int c = 0; c < 11; ++c) {
+#pragma omp atomic
+                            dg[c] += add[c];
+                        }
+                        for (int c = 0; c < 3; ++c) {
+#pragma omp atomic
+                            feat_grad[3 * (size_t)id + c] += (double)feat_add[c];
+                        }
+                    }
+                    for (int c = 0; c < 3; ++c) rgb_run[c] = run_after[c];
                     T = Tn;
-                    if (T < prm->min_transmittance) ray.alive = 0;
+                    if (flip_budget) {
+                        t_noise += h.alpha * nu / (1.0f - h.alpha) + 1.0f;   /* as in render_impl */
+                        if (fabsf(T - prm->min_transmittance) / (prm->min_transmittance * 5.9604645e-08f * t_noise) < flip_bound) term_prone = 1;
+                    }
+                    if (T < prm->min_transmittance && ray.alive) {
+                        ray.alive = 0;
+                        k_end = k + 1;
+                        ghost = flip_budget && term_prone;
+                    }
+                    if (ghost && T < 0.25f * prm->min_transmittance) ghost = 0;
                 }
-                if (k - beg > deepest) deepest = k - beg;
+                if (ray.alive) k_end = k;
+                if (k_end == 0) k_end = k;   /* (invalid id / end of list reached while alive) */
+                if (k_end - beg > deepest) deepest = k_end - beg;
             }
         traversed_total += deepest;
     }
     if (traversed_out) *traversed_out = traversed_total;
+}
+
+void oracle_render_bwd(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+                       const float* density12, const float* feat,
+                       const float* ray_ori, const float* ray_dir,
+                       const uint32_t* ranges, const uint32_t* sorted_ids,
+                       const float* rgba, const float* rgba_grad, const float* dist, const float* dist_grad,
+                       double* density_grad, double* feat_grad, uint64_t* traversed_out) {
+    render_bwd_impl(prm, cam, W, H, density12, feat, ray_ori, ray_dir, ranges, sorted_ids, rgba, rgba_grad, dist, dist_grad,
+                    density_grad, feat_grad, traversed_out, NULL, 0.0f);
+}
+
+/* the same backward, additionally exporting the per-Gaussian flip budget + fp32 conditioning [N,10] (see render_bwd_impl) — tests only */
+void oracle_render_bwd_budget(const OracleParams* prm, const OracleCamera* cam, int W, int H,
+                              const float* density12, const float* feat,
+                              const float* ray_ori, const float* ray_dir,
+                              const uint32_t* ranges, const uint32_t* sorted_ids,
+                              const float* rgba, const float* rgba_grad, const float* dist, const float* dist_grad,
+                              double* density_grad, double* feat_grad, uint64_t* traversed_out, double* flip_budget, float flip_bound) {
+    render_bwd_impl(prm, cam, W, H, density12, feat, ray_ori, ray_dir, ranges, sorted_ids, rgba, rgba_grad, dist, dist_grad,
+                    density_grad, feat_grad, traversed_out, flip_budget, flip_bound);
 }
 
 /* K8: projectBackward — gutProjector.cuh:390-430, gaussianParticles.cuh:120-187.

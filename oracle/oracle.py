@@ -184,8 +184,12 @@ def render_kbuffer(cam: dict, fwd: dict, K=16, params=None, max_order=0):
     return dict(rgba=rgba, dist=dist, hits=hits, order_ids=oi, order_count=oc)
 
 
-def backward(cam: dict, fwd: dict, rgba_grad, dist_grad, params=None):
-    """Backward for a forward() result. Returns (density_grad [N,12] f64, sph_grad [N,48] f64, feat_grad [N,3] f64)."""
+def backward(cam: dict, fwd: dict, rgba_grad, dist_grad, params=None, flip_bound=None):
+    """Backward for a forward() result. Returns (density_grad [N,12] f64, sph_grad [N,48] f64, feat_grad [N,3] f64).
+    flip_bound (e.g. 6.0): additionally returns, as a 4th element, [N,10] f64: columns 0..4 the per-Gaussian flip budget
+    (positions, density, rotation, scale, colour) — how far a different but equally valid fp32 evaluation may move each gradient
+    row because a hit / no-hit decision within `flip_bound` noise widths of its threshold flips — and columns 5..9 the fp32
+    conditioning of the same rows, sum over hits of eps * nu * |contribution| (gut_oracle.c: render_bwd_impl)."""
     L = lib()
     prm = params or default_params()
     c = make_camera(cam)
@@ -195,11 +199,20 @@ def backward(cam: dict, fwd: dict, rgba_grad, dist_grad, params=None):
     dens_g = np.zeros((N, 12), np.float64); feat_g = np.zeros((N, 3), np.float64)
     sph_g = np.zeros((N, 48), np.float64)
     trav = C.c_uint64(0)
-    if fwd["M"]:
+    budget = np.zeros((N, 10), np.float64) if flip_bound is not None else None
+    if fwd["M"] and budget is not None:
+        L.oracle_render_bwd_budget(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), _p(d12), _p(fwd["feat"]),
+                                   _p(ro), _p(rd), _p(fwd["tile_ranges"]), _p(fwd["sorted_ids"]),
+                                   _p(fwd["rgba"]), _p(rg), _p(fwd["dist"]), _p(dg), _p(dens_g), _p(feat_g), C.byref(trav),
+                                   _p(budget), C.c_float(float(flip_bound)))
+    elif fwd["M"]:
         L.oracle_render_bwd(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), _p(d12), _p(fwd["feat"]),
                             _p(ro), _p(rd), _p(fwd["tile_ranges"]), _p(fwd["sorted_ids"]),
                             _p(fwd["rgba"]), _p(rg), _p(fwd["dist"]), _p(dg), _p(dens_g), _p(feat_g), C.byref(trav))
+    if fwd["M"]:
         L.oracle_project_bwd(C.byref(c), C.c_uint32(N), C.c_int(sh_degree), _p(d12), _p(fwd["tiles_count"]),
                              _p(fwd["feat"]), _p(feat_g), _p(sph_g))
     fwd["traversed_bwd"] = int(trav.value)
+    if budget is not None:
+        return dens_g, sph_g, feat_g, budget
     return dens_g, sph_g, feat_g

@@ -234,3 +234,45 @@ def test_reference_undo_colour_backward_equals_the_true_derivative_without_negat
     (r1, a1, c1), (r2, a2, c2) = both(neg)
     assert float((r1 - r2).abs().max()) == 0 and float((c1 - c2).abs().max()) < 1e-13
     assert float((a1 - a2).abs().max()) > 1e-3
+
+
+def test_flip_budget_covers_what_a_threshold_perturbation_moves():
+    """oracle.backward(..., flip_bound=b) exports, per Gaussian, how far a flipped hit / no-hit decision may move each gradient
+    row (the allowance tests/common.check_gradient_rows grants the GPU per row).  Pinned here against an independent
+    experiment: the same backward with min_response and min_alpha moved by 1e-4 relative — every decision that flips under that
+    perturbation sits within 1e-4 / (eps * nu) <= 839 noise widths (nu >= 2), i.e. is flip-prone for b = 1000 — must stay within
+    tight fp32 terms + the budget on EVERY row, must actually move some rows (else the test is vacuous), and rows without a
+    budget must not move at all.  Also: asking for the budget does not change the gradients."""
+    from tests.common import GRAD_BLOCKS
+    sc = scenes.scene_c1(3000, 13)
+    sc["density"][::2] *= 0.02          # faint Gaussians: hits near the min_alpha threshold, where d alpha / d sigma ~ 1
+    W, H = 160, 128
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, 0.1, -3.0), (0, 0, 0)), fx=150)
+    d12 = scenes.pack_density(sc)
+    fwd = oracle.forward(view["oracle_cam"], W, H, d12, sc["features"], view["ro"], view["rd"])
+    rg = np.random.default_rng(3).normal(size=(H, W, 4)).astype(np.float32)
+    dg = np.zeros((H, W, 1), np.float32)
+    base = oracle.backward(view["oracle_cam"], fwd, rg, dg)
+    with_b = oracle.backward(view["oracle_cam"], fwd, rg, dg, flip_bound=1000.0)
+    assert all(np.allclose(base[j], with_b[j], rtol=1e-12, atol=1e-300) for j in range(3)) and np.abs(with_b[1]).max() > 0
+    budget = with_b[3]
+    assert budget.shape == (3000, 10) and (budget >= 0).all() and 0 < (budget[:, 1] > 0).sum() < 3000
+    none = oracle.backward(view["oracle_cam"], fwd, rg, dg, flip_bound=0.0)[3]
+    assert not none[:, :5].any() and np.allclose(none[:, 5:], budget[:, 5:], rtol=1e-12)
+    moved_rows = 0
+    for sign in (+1.0, -1.0):
+        prm = oracle.default_params()
+        prm.min_kernel_density *= (1.0 + sign * 1e-4)
+        prm.alpha_threshold *= (1.0 + sign * 1e-4)
+        fwd_p = oracle.forward(view["oracle_cam"], W, H, d12, sc["features"], view["ro"], view["rd"], params=prm)
+        pert = oracle.backward(view["oracle_cam"], fwd_p, rg, dg, params=prm)
+        blocks = [(base[0][:, sl], pert[0][:, sl]) for _, sl in GRAD_BLOCKS] + [(base[2], pert[2])]
+        for j, (a, b) in enumerate(blocks):
+            err = np.linalg.norm(a - b, axis=1)
+            nr = np.linalg.norm(a, axis=1)
+            scale = np.quantile(nr[nr > 0], 0.99)
+            bound = 1e-9 * nr + 1e-12 * scale + 2.0 * budget[:, j]
+            assert (err <= bound).all(), (sign, j, float((err / np.maximum(bound, 1e-300)).max()))
+            assert not err[budget[:, j] == 0].any()
+            moved_rows += int((err > 1e-9 * nr + 1e-12 * scale).sum())
+    assert moved_rows > 0

@@ -189,17 +189,21 @@ def _garden_worker(rank, world, port, out_dir):
             assert rel_l2(raw[:, sl].cpu().numpy(), ref_raw[:, sl].cpu().numpy()) <= 1e-4, (exchange, name)
         assert rel_l2(r["feats"].cpu().numpy(), ref_feats.cpu().numpy()) <= 1e-4, exchange
         # the UPDATE of two steps (parameters minus their start), element by element: Adam's step is ~ lr * sign(g) while the
-        # second moment is young, so an element whose gradient is pure float-atomic noise may differ by up to 2 lr; a wrong
-        # exchange (a view's records dropped, a chunk scattered to the wrong rows) would differ on every row the views touched
+        # second moment is young, so an element whose gradient is float-atomic noise, or sits on a Gaussian with a flipped
+        # hit / no-hit decision (the two paths activate the parameters with different exp / sigmoid implementations: last-ulp
+        # different inputs), may differ by up to 2 lr — measured: 1.8 % of the elements of the rows that moved; a wrong
+        # exchange (a view's records dropped, a chunk scattered to the wrong rows) would differ on every row a view touched
         moved = ((ref_raw - raw0).abs() > 0).any(1)
         assert int(moved.sum()) > 100_000
         differs = ((raw - ref_raw).abs() > 1e-6 + 1e-5 * ref_raw.abs())[moved]
         frac = float(differs.float().mean())
         upd = rel_l2((raw - raw0)[moved].cpu().numpy(), (ref_raw - raw0)[moved].cpu().numpy())
         print(f"[garden dp2 {exchange}] rows moved {int(moved.sum())}, elements differing {frac:.2e}, update rel-L2 {upd:.2e}")
-        assert frac <= 5e-3 and upd <= 5e-2, (exchange, frac, upd)
+        assert frac <= 5e-2 and upd <= 5e-2, (exchange, frac, upd)
     s_, d_ = results["sparse"], results["dense"]
-    assert rel_l2(s_["raw"].cpu().numpy(), d_["raw"].cpu().numpy()) <= 1e-6   # the two exchange forms carry the same sums
+    # the two exchange forms carry the same sums (two separate runs of the float-atomic backward: equal up to that noise)
+    assert rel_l2(s_["m12_1"].cpu().numpy(), d_["m12_1"].cpu().numpy()) <= 1e-4 and rel_l2(s_["m48_1"].cpu().numpy(), d_["m48_1"].cpu().numpy()) <= 1e-4
+    assert rel_l2(s_["raw"].cpu().numpy(), d_["raw"].cpu().numpy()) <= 1e-4
 
 
 def test_garden_workload_two_rank_step_at_full_size(tmp_path):

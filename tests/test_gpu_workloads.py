@@ -23,7 +23,7 @@ import pytest
 import torch
 
 import bench
-from tests.common import (cams, check_colour_outliers, check_gradients_per_row, check_side_stream_rows_are_gradient_free, make_view,
+from tests.common import (ROW_FLIP_BOUND, cams, check_colour_outliers, check_gradients_per_row, check_side_stream_rows_are_gradient_free, make_view,
                           rel_l2, scenes)
 
 pytestmark = pytest.mark.gpu
@@ -102,7 +102,7 @@ def test_workload_against_the_oracle(workload):
     rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
     dist_grad = (0.05 * rng.normal(size=(H, W, 1))).astype(np.float32)
     t0 = time.time()
-    dens_g, sph_g, _ = oracle.backward(ocam, ref, rgba_grad, dist_grad)
+    dens_g, sph_g, _, budget = oracle.backward(ocam, ref, rgba_grad, dist_grad, flip_bound=ROW_FLIP_BOUND)
     print(f"{workload}: oracle backward {time.time() - t0:.1f} s")
     b, sensor, poses, rgba_, dist_ = st._ctx
     g12 = torch.empty((n, 12), dtype=torch.float32, device=DEV)
@@ -114,7 +114,7 @@ def test_workload_against_the_oracle(workload):
     for name, sl in (("positions", slice(0, 3)), ("density", slice(3, 4)), ("rotation", slice(4, 8)), ("scale", slice(8, 11))):
         assert rel_l2(g12[:, sl], dens_g[:, sl]) <= 2e-3, f"{name}: {rel_l2(g12[:, sl], dens_g[:, sl])}"
     assert rel_l2(g48, sph_g) <= 2e-3
-    check_gradients_per_row(g12, g48, dens_g, sph_g, workload)
+    check_gradients_per_row(g12, g48, dens_g, sph_g, workload, budget)
     assert float(np.abs(g12[:, 11]).max()) == 0.0
     culled = ref["tiles_count"] == 0
     assert float(np.abs(g12[culled]).max()) == 0.0 and float(np.abs(g48[culled]).max()) == 0.0
