@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  # override: dev experiments only
 
-GUT_ABI_VERSION = 1
+GUT_ABI_VERSION = 3   # include/gut_hip.h: bumped on every struct / array-length / signature change
 GUT_NUM_KERNEL_TIMERS = 11
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
@@ -68,7 +68,8 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
            "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
            "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_compact_gradient_rows", "gut_scatter_gradient_records",
-           "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation")
+           "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation",
+           "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev")
 
 _lib = None
 
@@ -118,6 +119,7 @@ def load():
                                            vp, vp]
     lib.gut_optimize_rows_without_gradient.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float,
                                                        u32, vp]
+    lib.gut_optimize_finish_without_gradient.argtypes = [vp, vp]
     lib.gut_set_option.argtypes = [vp, i32, i32]
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
@@ -127,6 +129,7 @@ def load():
     lib.gut_adam_unwalked_waves.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float, u32, vp]
     lib.gut_compact_gradient_rows.argtypes = [vp, vp, vp, vp, u32, vp]
     lib.gut_scatter_gradient_records.argtypes = [vp, vp, u32, u32, vp, vp]
+    lib.gut_scatter_gradient_records_dev.argtypes = [vp, vp, vp, u32, u32, vp, vp]
     if lib.gut_abi_version() != GUT_ABI_VERSION:
         raise RuntimeError("libgut_hip.so ABI version mismatch; rebuild")
     _lib = lib

@@ -653,6 +653,9 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
         return fail("gut_trace_bwd: null pointer argument");
     if (num_particles && (!d_particle_density || (!(flags & GUT_BWD_SKIP_EPILOGUE) && (!d_particle_density_grad || !d_particle_radiance_grad))))
         return fail("gut_trace_bwd: null particle buffers");
+    if (h->early_ran && !(flags & GUT_BWD_SKIP_EPILOGUE))
+        return fail("gut_trace_bwd: gut_optimize_rows_without_gradient was called for this forward: the backward must be "
+                    "gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) followed by gut_optimize_after_bwd");
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
     gut::ViewParams v;
@@ -759,6 +762,37 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     h->early_ran = false;
     h->have_backward = false;  // the gradient rows are consumed ...
     h->grad16_zero = true;     // ... and left zero by the kernel
+    return 0;
+}
+
+int gut_optimize_finish_without_gradient(gut_handle h, void* stream_) {
+    if (!h) return fail("gut_optimize_finish_without_gradient: null handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->early_ran) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (h->fwd_stream != s) return fail("gut_optimize_finish_without_gradient: not the stream of the forward");
+    DeviceGuard dev_guard;
+    HIP_TRY(dev_guard.set(h->device));
+    const gut_context::EarlyArgs ea = h->early_args;
+    // discard whatever the backward compositor may have accumulated: every remaining wave sees an exactly-zero gradient
+    HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)h->n));
+    HIP_TRY(hipMemsetAsync(h->grad16.p, 0, h->grad16.cap, s));
+    if (launch_early_part2(h, s)) return 1;
+    gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, h->zero_word.as<float>() /* never read: no row has a colour gradient */,
+                                     h->grad16.as<float>(), h->tiles_count.as<uint32_t>(), h->feat.as<float>(), ea.raw12, ea.raw_m,
+                                     ea.raw_v, ea.sh48, ea.sh_m, ea.sh_v, ea.lr12, ea.lr48, ea.beta1, ea.beta2, ea.eps, ea.step, nullptr,
+                                     ea.act12, true, ea.extra_end ? h->wave_walked.as<uint8_t>() : nullptr, ea.block_begin, ea.extra_end);
+    HIP_TRY(hipGetLastError());
+    if (h->early_wait_pending) {
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_early_done, 0));
+        h->early_wait_pending = false;
+    }
+    h->stats_early = true;
+    h->stats_split = ea.block_begin;
+    h->stats_extra_end = ea.extra_end;
+    h->early_ran = false;
+    h->have_backward = false;
+    h->grad16_zero = true;
     return 0;
 }
 

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         // (sub-pixel or transparent), sprinkled between rows that have: row-granular, this pass visited 55 k such waves for
         // 13 % of its bytes with mostly-masked loads, and both passes touched those waves' cache lines.
         const bool mine = i < n;
+        if (wave_first >= n) continue;   // tail waves of the last 256-row block: no rows, and no entry in the per-wave flags
         // (tiles_count == nullptr: ownership by the wave flags alone — data-parallel runs, where the flags are the union over the
         //  ranks' views of the walked waves)
         const bool has_tiles = tiles_count ? (__ballot(i < n && tiles_count[i] != 0) != 0ull) : true;
@@ -464,9 +465,13 @@ __global__ __launch_bounds__(kBlock) void k_compact_gradient_rows(uint32_t n, co
     grad16[4 * (size_t)i + 0] = z; grad16[4 * (size_t)i + 1] = z; grad16[4 * (size_t)i + 2] = z; grad16[4 * (size_t)i + 3] = z;
 }
 
+// d_count != nullptr: the number of valid records is read on the device (at most `count` of them are taken): the data-parallel
+// step queues the scatter before the host knows the ranks' record counts (dp.RecordExchange)
 __global__ __launch_bounds__(kBlock) void k_scatter_gradient_records(const float4* __restrict__ records, uint32_t count, uint32_t n,
-                                                                    float4* __restrict__ grad12, float* __restrict__ mrgb_view) {
+                                                                    float4* __restrict__ grad12, float* __restrict__ mrgb_view,
+                                                                    const uint32_t* __restrict__ d_count) {
     const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (d_count) count = min(count, *d_count);
     if (r >= count) return;
     const float4 g0 = records[4 * (size_t)r + 0], g1 = records[4 * (size_t)r + 1], g2 = records[4 * (size_t)r + 2];
     const float4 m = records[4 * (size_t)r + 3];
@@ -722,7 +727,17 @@ int gut_scatter_gradient_records(void* stream, const float* d_records, uint32_t 
     if (!d_records || !d_raw_grad12 || !d_mrgb_view) return 1;
     hipLaunchKernelGGL(gut::k_scatter_gradient_records, dim3((count + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(d_records), count, num_particles,
-                       reinterpret_cast<float4*>(d_raw_grad12), d_mrgb_view);
+                       reinterpret_cast<float4*>(d_raw_grad12), d_mrgb_view, (const uint32_t*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int gut_scatter_gradient_records_dev(void* stream, const float* d_records, const uint32_t* d_count, uint32_t max_count,
+                                     uint32_t num_particles, float* d_raw_grad12, float* d_mrgb_view) {
+    if (max_count == 0) return 0;
+    if (!d_records || !d_count || !d_raw_grad12 || !d_mrgb_view) return 1;
+    hipLaunchKernelGGL(gut::k_scatter_gradient_records, dim3((max_count + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(d_records), max_count, num_particles,
+                       reinterpret_cast<float4*>(d_raw_grad12), d_mrgb_view, d_count);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

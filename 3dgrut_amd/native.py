@@ -20,7 +20,8 @@ import numpy as np
 import torch
 
 from . import _capi
-from .dp import allreduce_max_async, exchange_gradient_records, allgather_rows_, allgather_rows_async, allreduce_max_, allreduce_mean_, allreduce_sum_async
+from .dp import (RecordExchange, allgather_rows_, allgather_rows_async, allreduce_max_, allreduce_max_async, allreduce_mean_, allreduce_sum_async,
+                 assert_replicas_identical)
 from .losses import photometric_loss
 from .tracer import SplatRaster, Tracer
 
@@ -190,6 +191,11 @@ class NativeTrainStep:
         self._act_key = None
         self.rank = int(rank)
         self.force_exchange = os.environ.get("GUT_DP_FORCE_COLLECTIVES") == "1"  # see dp._skip
+        # sparse exchange: payload sized from the previous steps' record counts, counts consumed on the device (dp.RecordExchange)
+        self._exchange = RecordExchange(max(1, world_size))
+        # every replica_check_every steps (and on step 0) the ranks compare checksums of parameters and moments and raise if they
+        # differ (dp.assert_replicas_identical): nothing else would notice a diverged replica
+        self.replica_check_every = 500
         self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
         self.row_listeners = []         # callables(perm): told when reorder() re-sorts the rows (strategy statistics follow)
         self.resize_workspace()
@@ -223,7 +229,8 @@ class NativeTrainStep:
                 self.mrgb = [torch.zeros((w, r1 - r0, 3), dtype=torch.float32, device=dev) for r0, r1 in self.chunks]
                 self.records = torch.empty((max(n, 1), _capi.GRADIENT_RECORD_FLOATS), dtype=torch.float32, device=dev)
                 self.rec_count = torch.zeros(1, dtype=torch.int32, device=dev)
-                self._rec_scratch = {}
+                if getattr(self, "_exchange", None) is not None:
+                    self._exchange.reset()     # the number of Gaussians changed: no history to size the payload from
                 self.wave_flags = torch.zeros(((n + 63) // 64,), dtype=torch.uint8, device=dev)
                 self.exchanged_records = 0     # records received in the last step, all views (diagnostics / bench)
             else:
@@ -389,6 +396,20 @@ class NativeTrainStep:
         return {names[k]: acc[k] / n for k in range(len(names))}
 
     def step(self, batch):
+        try:
+            return self._step(batch)
+        except BaseException:
+            # The side-stream optimiser pass may already be running for this iteration (it is queued right behind the forward):
+            # finish the step for every other row with a zero gradient instead of leaving the parameters half advanced and the
+            # handle refusing the next forward (gut_optimize_finish_without_gradient); then let the error through.
+            try:
+                self.raster.finish_optimizer_step_without_gradient()
+                self._act_key = None
+            except Exception:
+                pass
+            raise
+
+    def _step(self, batch):
         m = self.model
         evs = [] if self.phase_timing else None
         self._mark(evs)
@@ -563,21 +584,38 @@ class NativeTrainStep:
                 allreduce_max_(vis, w)
         else:
             self.cams[0].copy_(cam_local)
-        gathered, counts = exchange_gradient_records(self.records, self.rec_count, w, self._rec_scratch)
+        # queued without reading anything back: counts all-gather, payload all-gather at the capacity carried from earlier steps,
+        # one scatter per view (rank order on every rank: identical summation order, identical replicas) with the view's record
+        # count taken on the device
+        ex = self._exchange
+        gathered, counts_dev, cap = ex.start(self.records, self.rec_count)
+        st = torch.cuda.current_stream(m.raw.device).cuda_stream
+        slabs = self.mrgb[0]
+        for v in range(gathered.shape[0]):
+            if cap:
+                rc = self._lib.gut_scatter_gradient_records_dev(C.c_void_p(st), gathered[v].data_ptr(), counts_dev.data_ptr() + 4 * v, cap, n,
+                                                                self.g12.data_ptr(), slabs[v].data_ptr())
+                if rc:
+                    raise RuntimeError(f"[3dgut] scatter_gradient_records failed ({rc})")
+        counts = ex.host_counts()         # everything above is queued: the GPU keeps working while the host waits for 4 W bytes
+        tail = ex.tail(self.records)      # a rank had more records than the capacity assumed: the rest, same order on every rank
+        if tail is not None:
+            for v, c in enumerate(tail[1]):
+                if c:
+                    rc = self._lib.gut_scatter_gradient_records(C.c_void_p(st), tail[0][v].data_ptr(), c, n, self.g12.data_ptr(),
+                                                                slabs[v].data_ptr())
+                    if rc:
+                        raise RuntimeError(f"[3dgut] scatter_gradient_records failed ({rc})")
         self.exchanged_records = int(sum(counts))
+        self.exchanged_bytes_per_rank = int(ex.payload_bytes_per_rank)
         if self.post_backward_hook is not None:  # per-view statistics of THIS rank's view (strategy/gs.py:106-115)
-            mine = gathered[self.rank if len(counts) > 1 else 0, :counts[self.rank if len(counts) > 1 else 0]]
+            r = self.rank if len(counts) > 1 else 0
+            mine = gathered[r, :min(counts[r], cap)]
+            if tail is not None and tail[1][r]:
+                mine = torch.cat([mine, tail[0][r, :tail[1][r]]])
             pg = torch.zeros((n, 3), dtype=torch.float32, device=m.raw.device)
             pg[mine[:, 11].contiguous().view(torch.int32).long()] = mine[:, 0:3]
             self.post_backward_hook(pg, cam_local)
-        st = torch.cuda.current_stream(m.raw.device).cuda_stream
-        slabs = self.mrgb[0]
-        for v, c in enumerate(counts):   # rank order on every rank: identical summation order, identical replicas
-            if c:
-                rc = self._lib.gut_scatter_gradient_records(C.c_void_p(st), gathered[v].data_ptr(), c, n, self.g12.data_ptr(),
-                                                            slabs[v].data_ptr())
-                if rc:
-                    raise RuntimeError(f"[3dgut] scatter_gradient_records failed ({rc})")
         vmask = vis.reshape(-1) if self.selective else None
         rc = self._lib.gut_sh_adam_step_ex(
             C.c_void_p(st), n, m.n_active_features, w, self.cams.data_ptr(), slabs.data_ptr(), self.g12.data_ptr(), 1.0 / w,
@@ -592,6 +630,9 @@ class NativeTrainStep:
         self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
 
     def _end_of_step(self, evs):
+        if self.world_size > 1 and self.replica_check_every and self.step_id % self.replica_check_every == 0:
+            assert_replicas_identical([self.model.raw, self.model.features, self.m12, self.v12, self.m48, self.v48], self.world_size,
+                                      what=f"after step {self.step_id}")
         if getattr(self, "_probe_evs", None) is not None:
             self._probe_evs[1].record()
             self._probe_evs = None

@@ -296,6 +296,15 @@ class SplatRaster:
                 int(step), None if act_out is None else act_out.data_ptr())
         _capi.check(rc, "optimize_rows_without_gradient")
 
+    def finish_optimizer_step_without_gradient(self):
+        """Ends a step that optimize_rows_without_gradient began and optimize_after_bwd cannot finish (something raised in
+        between): the remaining waves take the same Adam step with a zero gradient and the handle accepts trace() again
+        (gut_optimize_finish_without_gradient).  No-op when no step is half applied."""
+        dev = torch.device("cuda", self.device_index)
+        with torch.cuda.device(dev):
+            rc = self._lib.gut_optimize_finish_without_gradient(self._handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _capi.check(rc, "optimize_finish_without_gradient")
+
     def compact_gradient_rows(self, act12, records, count):
         """Per-Gaussian epilogue of trace_bwd(..., skip_epilogue=True) as a LIST: one 64-byte record per Gaussian with a
         non-zero gradient row (gut_compact_gradient_rows; layout in gut_hip.h).  records: float32 [>= N, 16] on the device,

@@ -131,7 +131,7 @@ def cpu_baseline_per_ray_torch(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degr
     centred crop; the Gaussian set is culled with the UT projection rule to the ones whose 2-D extent touches the
     crop (otherwise brute force over all 6 M).  The crop doubles until ~budget_s of CPU work is reached."""
     prt = importlib.import_module("oracle.per_ray_torch")
-    threads = max(1, min(os.cpu_count() or 1, 32))
+    threads = max(1, os.cpu_count() or 1)   # every host core (BASELINE.md §3)
     torch.set_num_threads(threads)
     tq = pose_mod.sensor_pose_from_c2w(c2w).T_world_sensors[0]
     cam = dict(model="pinhole", principal_point=[W / 2, H / 2], focal_length=[fx, fx])
@@ -205,7 +205,7 @@ def self_launch(argv, n_gpus):
 def profile_counters():
     """Per-kernel PMC counters of the tracked profile of this command (profiles/<latest round>/pmc_traffic.json, pmc_sq.json)."""
     out = {}
-    for rnd in ("round2", "round1"):
+    for rnd in ("round3", "round2", "round1"):
         d = os.path.join(ROOT, "profiles", rnd)
         if not os.path.isfile(os.path.join(d, "pmc_traffic.json")):
             continue
@@ -220,6 +220,33 @@ def profile_counters():
         except Exception:
             out = {}
     return out
+
+
+def data_label(args):
+    """The `data` field of the JSON line."""
+    if getattr(args, "ply", None):
+        return "ply:" + os.path.basename(args.ply) + ((" colmap:" + os.path.basename(os.path.normpath(args.colmap))) if args.colmap else "")
+    return "synthetic"
+
+
+def load_scene(args, workload, kw=None):
+    """(scene dict, ColmapScene or None, scene extent) of a run: the named workload's seeded stand-in, or — `--ply PATH` — a real
+    scene in its place ("real scenes substitute 1:1 if supplied as PLY"; threedgrut/model/model.py:671-719 layout),
+    optionally with a COLMAP directory's training views instead of the workload's orbit cameras (`--colmap DIR`)."""
+    scenes = importlib.import_module("3dgrut_amd.scenes")
+    fn, wkw, W, H, fx, radius, elev, extent = WORKLOADS[workload]
+    if getattr(args, "ply", None) and workload == args.workload:
+        io_ply = importlib.import_module("3dgrut_amd.io_ply")
+        scene = io_ply.scene_from_ply(args.ply)
+        colmap = None
+        if getattr(args, "colmap", None):
+            io_colmap = importlib.import_module("3dgrut_amd.io_colmap")
+            colmap = io_colmap.ColmapScene(args.colmap, split="train", downsample_factor=getattr(args, "colmap_downsample", 1))
+            if len(colmap) == 0:
+                raise SystemExit(f"--colmap {args.colmap}: no training views")
+            extent = colmap.cameras_extent
+        return scene, colmap, extent
+    return getattr(scenes, fn)(**(wkw if kw is None else kw)), None, extent  # same seed on every rank -> identical replicas
 
 
 def synthetic_optimizer_state(stepper):
@@ -246,7 +273,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     kw = dict(kw)
     if args.num_gaussians:
         kw["n"] = args.num_gaussians
-    scene = getattr(scenes, fn)(**kw)  # same seed on every rank -> identical replicas
+    scene, colmap, extent = load_scene(args, workload, kw)
     sh_degree = 3
     tracer = gut.Tracer({"render": {"enable_kernel_timings": True}})
     if args.full_sort:
@@ -284,8 +311,19 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     gt = torch.stack([0.5 + 0.4 * torch.sin(6.0 * xx), 0.5 + 0.4 * torch.cos(5.0 * yy), 0.5 * (xx + yy)], -1)
     gt = (gt + 0.02 * torch.randn(gt.shape, generator=g)).clamp(0, 1)[None].to(dev)
 
+    colmap_batches = {}
+
     def batch_for(step):
         v = dp_mod.view_index(step, rank, world, n_views)
+        if colmap is not None:   # the scene's own training views (cached on the device); targets: the image if it is there
+            i = v % len(colmap)
+            if i not in colmap_batches:
+                b = colmap.batch(i, device=dev, pose_on_host=args.host_pose)
+                if b.rgb_gt is None:
+                    hh, ww = b.rays_dir.shape[1], b.rays_dir.shape[2]
+                    b.rgb_gt = torch.nn.functional.interpolate(gt.permute(0, 3, 1, 2), size=(hh, ww), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+                colmap_batches[i] = b
+            return colmap_batches[i]
         # the 4x4 pose stays on the host (the tracer needs it there to fill the camera struct; a device tensor would
         # cost a blocking read-back per step, as in the reference's tracer.py:353-356)
         pose = torch.as_tensor(c2ws[v])[None] if args.host_pose else torch.as_tensor(c2ws[v], device=dev)[None]
@@ -298,6 +336,12 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
 
     for s in range(warmup):
         stepper.step(batch_for(s))
+    # the trainer's overlap probe times steps 1..4 in alternating forms and decides at step 5: never inside the timed region
+    extra_warmup = 0
+    while getattr(stepper, "_overlap_probe", None) is not None and not stepper._overlap_probe["done"] and extra_warmup < 8:
+        stepper.step(batch_for(warmup + extra_warmup))
+        extra_warmup += 1
+    warmup += extra_warmup
     raster = tracer.tracer_wrapper
     barrier()
     raster.kernel_times_mean()  # reset the per-kernel event ring
@@ -330,7 +374,33 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     return dict(value=world * steps / elapsed, ms_per_step=1000.0 * elapsed / steps, phases=phases,
                 step_spans=getattr(stepper, "last_step_spans_ms", None), ktimes=ktimes, kcount=kcount, fb=fb,
                 stats=stats, render_ms=render_ms, scene=scene, cams=cams, pose_mod=pose_mod, c2ws=c2ws, W=W, H=H, fx=fx,
-                fisheye=fisheye, stepper=stepper)
+                fisheye=fisheye, stepper=stepper, extra_warmup=extra_warmup, colmap=colmap is not None, extent=extent,
+                batch_for=batch_for, tracer=tracer, dev=dev)
+
+
+def run_drop_in(res, steps=8, warmup=3):
+    """The SAME workload through the reference's own surface, untouched trainer side: Tracer.render -> Tracer._Autograd ->
+    torch loss -> loss.backward() -> torch.optim.Adam (3dgrut_amd/train.TrainStep = trainer.py:705-778 with only the renderer
+    swapped).  This is what a user of threedgrut.trainer gets by switching the plugin; `value` above additionally needs the
+    trainer to call the gut_optimize_* entry points."""
+    model_mod = importlib.import_module("3dgrut_amd.model")
+    train_mod = importlib.import_module("3dgrut_amd.train")
+    dev = res["dev"]
+    model = model_mod.GaussianModel(res["scene"], device=dev, sh_degree=3)
+    stepper = train_mod.TrainStep(model, res["tracer"], scene_extent=res["extent"], world_size=1)
+    for s in range(warmup):
+        stepper.step(res["batch_for"](s))
+    torch.cuda.synchronize(dev)
+    res["tracer"].tracer_wrapper.collect_times()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        stepper.step(res["batch_for"](warmup + s))
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    fb = res["tracer"].tracer_wrapper.collect_times()
+    return {"trainer": "autograd (Tracer.render -> _Autograd -> torch.optim.Adam(fused)), the reference's surface unchanged",
+            "value": steps / dt, "unit": "images/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps, "warmup": warmup,
+            "forward_render_ms": fb.get("forward_render"), "backward_render_ms": fb.get("backward_render")}
 
 
 def main():
@@ -367,9 +437,18 @@ def main():
                          "(non-zero moments on every row) the headline is measured in")
     ap.add_argument("--early-extra", type=int, default=None,
                     help="GUT_OPT_EARLY_EXTRA_PERCENT (0..100): share of the row blocks in which the side stream also takes the waves "
-                         "with tiles the forward walked nothing of (library default 25)")
+                         "with tiles the forward walked nothing of (library default 100)")
     ap.add_argument("--no-placement-tuning", action="store_true",
                     help="keep the trainer state where the allocator first put it (default: NativeTrainStep.tune_placement, best of eight)")
+    ap.add_argument("--ply", default=None,
+                    help="render / train THIS scene instead of the synthetic stand-in: a 3DGS-compatible PLY (threedgrut/model/model.py:"
+                         "671-719 layout, 3dgrut_amd/io_ply.py); cameras are the named workload's orbit unless --colmap is given")
+    ap.add_argument("--colmap", default=None,
+                    help="with --ply: a COLMAP scene directory (sparse/0 + images[_N]/): its training views (poses, intrinsics, images "
+                         "as targets where present) replace the orbit cameras (3dgrut_amd/io_colmap.py)")
+    ap.add_argument("--colmap-downsample", type=int, default=1, help="images_<N>/ and intrinsics / N (MipNeRF360 runs use 4 for bicycle)")
+    ap.add_argument("--no-drop-in", action="store_true",
+                    help="skip the short second measurement through the reference's own surface (Tracer.render -> _Autograd -> torch.optim.Adam)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
                     help="one optimiser kernel after the backward instead of the side-stream pass for the waves that cannot receive a gradient")
     args = ap.parse_args()
@@ -437,7 +516,7 @@ def main():
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
         # PMC counters are NOT collected in this run (rocprofv3 --pmc needs its own passes): they are replayed from the
         # tracked profile of the same command and workload, and say so
-        prof = profile_counters() if (args.workload == "bicycle_like_6M_1237x822" and not args.num_gaussians
+        prof = profile_counters() if (args.workload == "bicycle_like_6M_1237x822" and not args.num_gaussians and not args.ply
                                       and args.trainer == "native" and not args.scene_order) else {}
         pk = lambda k: prof.get(k, {})
         traffic = pk(dom).get("hbm_bytes")
@@ -487,7 +566,7 @@ def main():
             "metric": "train-step images/sec + render ms/frame, MipNeRF360 bicycle @1/2/4/8 GPU",
             "value": res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, host-staged exchange - not a bench line)"
+            "dtype": "f32", "data": data_label(args) + (" (REHEARSAL: ranks share GPUs, host-staged exchange - not a bench line)"
                                                       if os.environ.get("GUT_BENCH_SHARE_GPU") == "1" else ""),
             "config": {"workload": args.workload, "num_gaussians": int(stats["num_particles"]), "resolution": [W, H],
                        "sh_degree": sh_degree, "views_per_step": world, "parallelism": f"per-view dp{world}" + ("" if world == 1 else (" dense all-reduce [N,60]" if (args.dense_exchange or args.trainer != "native") else (" sparse exchange: all-gather of 64-byte gradient records" if args.dp_exchange == "sparse" else " all-reduce [N,12] + all-gather [N,3]"))),
@@ -508,7 +587,26 @@ def main():
             "phase_ms": res["phases"], "step_gpu_span_ms": res["step_spans"], "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
             "reference_rtx5090": {"images_per_s": 31.6, "render_ms": 3.64, "note": "README.md:320, different hardware, real dataset"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1 or args.force_exchange:
+            # what the communicator looked like from rank 0, so that "did RCCL see N ranks" can be read off the line
+            dp_mod = importlib.import_module("3dgrut_amd.dp")
+            out["collective"] = dict(dp_mod.collective_info(world), exchange=args.dp_exchange if args.trainer == "native" and not args.dense_exchange else "dense [N,60]",
+                                     exchanged_bytes_per_rank=getattr(stepper, "exchanged_bytes_per_rank", None),
+                                     exchanged_records_last_step=getattr(stepper, "exchanged_records", None),
+                                     record_capacity_overflows=getattr(getattr(stepper, "_exchange", None), "overflows", None),
+                                     replica_check="checksums of parameters and moments MIN/MAX-reduced on step 0 (passed, or this line would not exist)",
+                                     hardware_status="the N > 1 path has run on multi-GPU hardware only in the driver's own scaling runs; "
+                                                     "builder-side it is covered by gloo world-2/3 tests and two-process one-GPU tests")
+        out["config"]["warmup_extended_by"] = res.get("extra_warmup", 0)
+        if world == 1 and not args.no_drop_in and args.trainer == "native":
+            try:
+                out["drop_in"] = run_drop_in(res)
+            except Exception as e:
+                out["drop_in"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_cpu_baseline and res.get("colmap"):
+            out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "not run: the CPU legs are wired for the named workloads' orbit cameras, not for --colmap views"}
+        elif world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(res["scene"], res["cams"], res["pose_mod"], W, H, fx, res["c2ws"][0], sh_degree,
                                                    fisheye=res["fisheye"])
@@ -522,15 +620,15 @@ def main():
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         # workload sensitivity: the same train step on the denser stand-in with SURVEY §8d C3's literal parameters
         # (a short, labelled second measurement; `value` above stays the headline workload)
-        if world == 1 and args.workload == "bicycle_like_6M_1237x822" and not args.no_sensitivity and not args.num_gaussians:
+        if world == 1 and args.workload == "bicycle_like_6M_1237x822" and not args.no_sensitivity and not args.num_gaussians and not args.ply:
             try:
                 del res, stepper
                 torch.cuda.empty_cache()
-                r2 = run_workload(args, env, "bicycle_like_6M_survey_c3", 10, 3, 5)
+                r2 = run_workload(args, env, "bicycle_like_6M_survey_c3", 10, 5, 5)   # (+ warm-up extended until the overlap probe has decided)
                 out["sensitivity"] = {"workload": "bicycle_like_6M_survey_c3",
                                       "note": "same step on the stand-in generated with SURVEY.md §8d C3's literal parameters (log-normal scales "
                                               "mu = ln 0.01, opacity logits N(0, 1.5)): larger, more opaque splats, far more tile intersections",
-                                      "value": r2["value"], "unit": "images/s", "ms_per_step": r2["ms_per_step"], "steps": 10, "warmup": 3,
+                                      "value": r2["value"], "unit": "images/s", "ms_per_step": r2["ms_per_step"], "steps": 10, "warmup": 5 + r2.get("extra_warmup", 0),
                                       "render_ms_per_frame": r2["render_ms"], "phase_ms": r2["phases"], "scene_stats": r2["stats"],
                                       "per_kernel_ms": {k: v for k, v in r2["ktimes"].items()}}
             except Exception as e:

@@ -6,9 +6,11 @@
  *   - every pointer named d_* is a DEVICE pointer owned by the caller (torch tensors in the Python
  *     shim); the library never retains them past the call.  Scratch (per-Gaussian projection
  *     buffers, tile keys, sort temporaries) is owned by the handle and is grow-only.
- *   - `stream` is a hipStream_t passed as void*; all work of a call is enqueued on it.  trace() does
- *     one 4-byte device->host readback + stream synchronise (the intersection count), exactly like
- *     the reference (src/gutRenderer.cu:313-321).
+ *   - `stream` is a hipStream_t passed as void*; all work of a call is enqueued on it.  The reference blocks in the middle
+ *     of its forward on a 4-byte device->host read-back of the intersection count (src/gutRenderer.cu:313-321); here only
+ *     the FIRST trace() on a handle does: afterwards the binning buffers are sized from the previous frames' counts, the
+ *     whole forward is queued, and the host reads the count back behind it (a frame that needed more is binned and
+ *     composited a second time; GutStats.binning_overflows counts those).
  *   - return value 0 = success; anything else is an error and gut_last_error() describes it
  *     (the reference logs and drops its Status codes, splatRaster.cpp:225-237; pybind turns C++
  *     exceptions into RuntimeError — the Python shim raises RuntimeError on non-zero).
@@ -26,7 +28,10 @@
 extern "C" {
 #endif
 
-#define GUT_ABI_VERSION 1
+/* Bumped on every change of a struct layout, an array length or an entry point's signature (2: GutStats grew to 80 bytes and
+ * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: gut_optimize_finish_without_gradient, gut_trace_fields / gut_trace_bwd_fields,
+ * the tile partition replaces the radix passes behind GUT_BUF_*). */
+#define GUT_ABI_VERSION 3
 
 typedef struct gut_context* gut_handle;
 
@@ -293,6 +298,14 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream, float* d_raw1
                                        float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* d_act12_out);
 
+/* Ends an optimiser step that gut_optimize_rows_without_gradient began but gut_optimize_after_bwd cannot finish (the caller's
+ * loss raised, the backward was rejected, ...): every wave the side stream does not own takes the same Adam step with an
+ * exactly-zero gradient (whatever the backward compositor may already have accumulated for this view is discarded and the
+ * gradient rows are left zero), the caller's stream is ordered behind the side stream, and the handle accepts gut_trace again.
+ * Afterwards every row has taken exactly one step of iteration `step`, as if the view had given no gradient at all.  No-op
+ * (returns 0) when no step is half applied. */
+int gut_optimize_finish_without_gradient(gut_handle h, void* stream);
+
 /* ---- Sparse gradient exchange of the data-parallel trainer (new functionality, the reference is single-GPU) ----
  * A view gives a gradient only to the Gaussians its rays hit.  Instead of dense [N,12] + [N,3] tensors per view, the ranks
  * exchange lists of 64-byte records, one per Gaussian with a non-zero gradient row:
@@ -316,6 +329,10 @@ int gut_compact_gradient_rows(gut_handle h, void* stream, const float* d_particl
                               uint32_t* d_count);
 int gut_scatter_gradient_records(void* stream, const float* d_records, uint32_t count, uint32_t num_particles, float* d_raw_grad12,
                                  float* d_mrgb_view);
+/* the same with the number of valid records read ON THE DEVICE: min(*d_count, max_count) records are taken.  Lets the caller
+ * queue the scatter before the host has seen the ranks' record counts (3dgrut_amd/dp.py: RecordExchange). */
+int gut_scatter_gradient_records_dev(void* stream, const float* d_records, const uint32_t* d_count, uint32_t max_count,
+                                     uint32_t num_particles, float* d_raw_grad12, float* d_mrgb_view);
 int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree, uint32_t num_views,
                         const float* d_camera_positions, float* d_mrgb, float* d_raw_grad12, float grad_scale,
                         float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,

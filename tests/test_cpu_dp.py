@@ -52,34 +52,69 @@ def test_single_rank_is_a_no_op():
     assert torch.equal(t, torch.ones(4)) and dp.view_index(5, 0, 1, 4) == 1
 
 
+COUNTS = [(5, 40, 0), (0, 0, 0), (300, 7, 12), (20, 280, 3), (1, 2, 3)]   # ragged, all empty, beyond the carried capacity, within it
+
+
 def _records_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    scratch = {}
+    ex = dp.RecordExchange(world, min_capacity=8, granule=8)
     outs = []
-    for step, counts in enumerate([(5, 40, 0), (0, 0, 0), (300, 7, 12)]):   # ragged, all empty, receive buffer regrown
+    for step, counts in enumerate(COUNTS):
         g = torch.Generator().manual_seed(1000 * step + rank)
         rec = torch.randn((300, 16), generator=g)          # capacity = "number of Gaussians"; rows beyond the count are stale
-        gathered, got = dp.exchange_gradient_records(rec, torch.tensor([counts[rank]], dtype=torch.int32), world, scratch)
-        outs.append(dict(counts=got, rows=[gathered[r, :got[r]].clone() for r in range(world)], mine=rec[:counts[rank]].clone()))
+        cap_before = ex.capacity
+        gathered, counts_dev, cap = ex.start(rec, torch.tensor([counts[rank]], dtype=torch.int32))
+        # what gut_scatter_gradient_records_dev would take from the payload: min(count, capacity) records per view
+        rows = [gathered[r, :min(int(counts_dev[r]), cap)].clone() for r in range(world)]
+        got = ex.host_counts()
+        tail = ex.tail(rec)
+        if tail is not None:
+            rows = [torch.cat([rows[r], tail[0][r, :tail[1][r]]]) for r in range(world)]
+        outs.append(dict(counts=got, rows=rows, mine=rec[:counts[rank]].clone(), cap_before=cap_before, cap=cap, overflowed=tail is not None,
+                         bytes=ex.payload_bytes_per_rank))
     torch.save(outs, os.path.join(out_dir, f"rec{rank}.pt"))
+    # replica comparison: identical tensors pass, one differing bit raises on every rank
+    same = [torch.arange(12.0).reshape(3, 4), torch.ones(5)]
+    dp.assert_replicas_identical(same, world)
+    diff = [t.clone() for t in same]
+    if rank == 1:
+        diff[1][2] = 1.0000001
+    try:
+        dp.assert_replicas_identical(diff, world, what="test")
+        raised = False
+    except RuntimeError as e:
+        raised = "tensors [1] differ" in str(e)
+    torch.save(dict(raised=raised, info=dp.collective_info(world)), os.path.join(out_dir, f"chk{rank}.pt"))
     dist.barrier(); dist.destroy_process_group()
 
 
 def test_three_rank_sparse_record_exchange(tmp_path):
-    """exchange_gradient_records: every rank ends with every rank's records (ragged counts, zero counts), bit-identical."""
+    """RecordExchange: every rank ends with every rank's records (ragged counts, zero counts, a step whose counts exceed the
+    capacity carried from earlier steps -> tail exchange), bit-identical; the payload is sized from PREVIOUS steps' counts."""
     world = 3
     mp.spawn(_records_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     r = [torch.load(os.path.join(tmp_path, f"rec{k}.pt")) for k in range(world)]
-    for step, counts in enumerate([(5, 40, 0), (0, 0, 0), (300, 7, 12)]):
+    for step, counts in enumerate(COUNTS):
         for k in range(world):
             assert r[k][step]["counts"] == list(counts)
             for src in range(world):
                 assert r[k][step]["rows"][src].shape == (counts[src], 16)
                 assert torch.equal(r[k][step]["rows"][src], r[src][step]["mine"])
+    s = r[0]
+    assert s[0]["cap_before"] == 0 and s[0]["cap"] == 64 and not s[0]["overflowed"]          # first step: sized from its own counts (40 * 1.25 + 8)
+    assert s[1]["cap"] == 64 and s[2]["cap"] == 64 and s[2]["overflowed"]                   # 300 > 64: tail exchange
+    assert s[3]["cap"] == 300 and not s[3]["overflowed"]                                     # capacity followed the peak (clamped to the buffer)
+    assert s[4]["cap"] == 300 and s[4]["bytes"] == world * 300 * 64
+    chk = [torch.load(os.path.join(tmp_path, f"chk{k}.pt")) for k in range(world)]
+    assert all(c["raised"] for c in chk)
+    assert chk[0]["info"]["backend"] == "gloo" and chk[0]["info"]["world_size_seen"] == world
 
 
-def test_single_rank_record_exchange_is_a_view():
+def test_single_rank_record_exchange():
     rec = torch.arange(64.0).reshape(4, 16)
-    gathered, counts = dp.exchange_gradient_records(rec, torch.tensor([3], dtype=torch.int32), 1, {})
-    assert counts == [3] and gathered.shape == (1, 3, 16) and gathered.data_ptr() == rec.data_ptr()
+    ex = dp.RecordExchange(1, min_capacity=2, granule=2)
+    gathered, counts_dev, cap = ex.start(rec, torch.tensor([3], dtype=torch.int32))
+    assert ex.host_counts() == [3] and int(counts_dev[0]) == 3 and cap == 4 and torch.equal(gathered[0, :3], rec[:3]) and ex.tail(rec) is None
+    dp.assert_replicas_identical([rec], 1)
+    assert dp.collective_info(1)["world_size_seen"] == 1

@@ -197,3 +197,30 @@ def test_spatial_permutation_matches_the_numpy_morton_order():
     perm = native.spatial_permutation(torch.as_tensor(pts)).numpy()
     assert np.array_equal(perm, scenes.morton_order(pts))
     assert np.array_equal(np.sort(perm), np.arange(5000))
+
+
+def test_bench_takes_a_real_scene_as_ply_and_colmap(tmp_path):
+    """bench.py --ply PATH [--colmap DIR]: the scene the bench builds its model from is the PLY's, row for row, the views are the
+    COLMAP directory's training split, and the line says so in `data` (real scenes substitute the stand-ins 1:1)."""
+    import argparse
+    import bench
+    sc = scenes.scene_c1(300, 5)
+    m = native.NativeGaussianModel(sc, device="cpu")
+    ply = os.path.join(str(tmp_path), "point_cloud.ply")
+    io_ply.export_native_model(m, ply)
+    _synthetic_colmap(str(tmp_path))
+    args = argparse.Namespace(ply=ply, colmap=str(tmp_path), colmap_downsample=1, workload="bicycle_like_6M_1237x822")
+    scene, colmap, extent = bench.load_scene(args, "bicycle_like_6M_1237x822")
+    assert scene["positions"].shape == (300, 3) and np.allclose(scene["positions"], sc["positions"])
+    assert np.allclose(scene["scale"], sc["scale"], rtol=1e-5) and np.allclose(scene["density"], np.clip(sc["density"], 1e-6, 1 - 1e-6), rtol=1e-4, atol=1e-6)
+    assert np.allclose(scene["features"], sc["features"])
+    assert len(colmap) == 7 and abs(extent - colmap.cameras_extent) == 0 and extent > 0
+    b = colmap.batch(0, device="cpu")
+    assert b.rays_dir.shape[0] == 1 and b.rays_dir.shape[3] == 3
+    assert bench.data_label(args) == "ply:point_cloud.ply colmap:" + os.path.basename(os.path.normpath(str(tmp_path)))
+    # without --ply: the seeded stand-in of the named workload (a tiny one here)
+    plain = argparse.Namespace(ply=None, colmap=None, workload="c1_1k_128x128")
+    scene2, colmap2, extent2 = bench.load_scene(plain, "c1_1k_128x128")
+    assert scene2["positions"].shape == (1000, 3) and colmap2 is None and extent2 == 1.0 and bench.data_label(plain) == "synthetic"
+    # the sensitivity workload of a --ply run is not the PLY
+    assert bench.load_scene(argparse.Namespace(ply=ply, colmap=None, workload="c1_1k_128x128"), "lego_like_300k_800x800", dict(n=10, seed=1))[0]["positions"].shape[0] == 10

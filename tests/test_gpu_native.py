@@ -436,6 +436,50 @@ def test_half_applied_optimiser_step_is_an_error():
         ovl.forward(b)
 
 
+def test_a_failing_step_is_finished_with_a_zero_gradient():
+    """Something raises between the side-stream optimiser pass and gut_optimize_after_bwd (here: a loss that rejects its
+    target): NativeTrainStep.step finishes the iteration for every other row with a zero gradient
+    (gut_optimize_finish_without_gradient), the error still reaches the caller, the handle renders again, and the state is
+    EXACTLY one zero-gradient Adam step of every row — what gut_adam_unwalked_waves computes with all-zero wave flags."""
+    sc, (_, ovl) = _native_pair(n=3000)
+    view = make_view("pinhole", 96, 64, cams.look_at_c2w((0.1, 0, -3.5), (0, 0, 0)), fx=90.0)
+    good = to_batch(view, DEV); good.rgb_gt = torch.rand((1, 64, 96, 3), generator=torch.Generator().manual_seed(2)).to(DEV)
+    ovl.step(good); ovl.step(good)                       # non-trivial moments
+    n = ovl.model.num_gaussians
+    state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48)
+    exp = {k: v.clone() for k, v in state(ovl).items()}
+    exp_act = torch.empty_like(ovl.act)
+    lib = capi.load()
+    f32p = C.POINTER(C.c_float)
+    rc = lib.gut_adam_unwalked_waves(C.c_void_p(torch.cuda.current_stream().cuda_stream), n, torch.zeros((n + 63) // 64, dtype=torch.uint8, device=DEV).data_ptr(),
+                                     exp["raw"].data_ptr(), exp["m12"].data_ptr(), exp["v12"].data_ptr(), exp["features"].data_ptr(),
+                                     exp["m48"].data_ptr(), exp["v48"].data_ptr(), ovl.lr12.ctypes.data_as(f32p), ovl.lr48.ctypes.data_as(f32p),
+                                     ovl.betas[0], ovl.betas[1], ovl.eps, ovl.step_id + 1, exp_act.data_ptr())
+    assert rc == 0
+    bad = to_batch(view, DEV); bad.rgb_gt = "not a tensor"
+    with pytest.raises(AttributeError):
+        ovl.step(bad)
+    torch.cuda.synchronize()
+    for k, v in state(ovl).items():
+        assert torch.equal(v, exp[k]), k
+    ovl.forward(good)                                    # the handle is usable again ...
+    assert torch.equal(ovl.act, exp_act)                 # ... and the activation rows follow the updated parameters
+    ovl.step(good)
+    assert bool(torch.isfinite(ovl.model.raw).all())
+    # a plain (non-SKIP_EPILOGUE) backward after the side-stream call is rejected at once, not at the next forward
+    ovl.forward(good)
+    m = ovl.model
+    ovl.raster.optimize_rows_without_gradient(m.raw, ovl.m12, ovl.v12, m.features, ovl.m48, ovl.v48, ovl.lr12, ovl.lr48, ovl.betas, ovl.eps,
+                                              ovl.step_id + 1, ovl.act)
+    b_, sensor, poses, rgba, dist_ = ovl._ctx
+    with pytest.raises(RuntimeError, match="GUT_BWD_SKIP_EPILOGUE"):
+        ovl.raster.trace_bwd(ovl.step_id, m.n_active_features, ovl.act, m.features, b_.rays_ori.contiguous(), b_.rays_dir.contiguous(), None,
+                             sensor, poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1],
+                             rgba, torch.zeros_like(rgba), dist_, None)
+    ovl.raster.finish_optimizer_step_without_gradient()
+    ovl.forward(good)
+
+
 def test_spatial_storage_order_is_transparent():
     """NativeGaussianModel(spatial_order=True) only permutes the rows: same image, and after two train steps the parameters
     are those of the scene-order model, row for row through `permutation` (up to the float-atomic noise of the backward);
