@@ -63,13 +63,17 @@ class GutStats(C.Structure):
     ]
 
 
+class GutLazyMoments(C.Structure):
+    _fields_ = [("d_wave_step", C.c_void_p), ("d_pow_beta1", C.c_void_p), ("d_pow_beta2", C.c_void_p), ("table_len", C.c_uint32)]
+
+
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",
            "gut_get_stats", "gut_debug_buffer", "gut_debug_copy", "gut_kernel_times", "gut_kernel_times_mean", "gut_last_error", "gut_abi_version",
            "gut_ssim_workspace_bytes", "gut_ssim_forward", "gut_ssim_backward",
            "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
            "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_compact_gradient_rows", "gut_scatter_gradient_records",
            "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation",
-           "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev")
+           "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev", "gut_adam_unwalked_waves_ex", "gut_sync_moments")
 
 _lib = None
 
@@ -115,18 +119,21 @@ def load():
     lib.gut_adam_step.argtypes = [vp, C.c_uint64, u32, vp, vp, vp, vp, C.POINTER(C.c_float), C.c_float, C.c_float,
                                   C.c_float, u32, vp]
     fptr = C.POINTER(C.c_float)
+    lazy_p = C.POINTER(GutLazyMoments)
     lib.gut_optimize_after_bwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float, u32,
-                                           vp, vp]
+                                           vp, vp, lazy_p]
     lib.gut_optimize_rows_without_gradient.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float,
-                                                       u32, vp]
+                                                       u32, vp, lazy_p]
+    lib.gut_sync_moments.argtypes = [vp, u32, vp, vp, vp, vp, lazy_p, u32]
     lib.gut_optimize_finish_without_gradient.argtypes = [vp, vp]
     lib.gut_set_option.argtypes = [vp, i32, i32]
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,
                                      C.c_float, C.c_float, C.c_float, u32, vp, vp, u32]
-    lib.gut_sh_adam_step_ex.argtypes = lib.gut_sh_adam_step.argtypes + [u32, vp]
+    lib.gut_sh_adam_step_ex.argtypes = lib.gut_sh_adam_step.argtypes + [u32, vp, lazy_p]
     lib.gut_mark_walked_waves.argtypes = [vp, vp, vp]
     lib.gut_adam_unwalked_waves.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp, fptr, fptr, C.c_float, C.c_float, C.c_float, u32, vp]
+    lib.gut_adam_unwalked_waves_ex.argtypes = lib.gut_adam_unwalked_waves.argtypes + [lazy_p]
     lib.gut_compact_gradient_rows.argtypes = [vp, vp, vp, vp, u32, vp]
     lib.gut_scatter_gradient_records.argtypes = [vp, vp, u32, u32, vp, vp]
     lib.gut_scatter_gradient_records_dev.argtypes = [vp, vp, vp, u32, u32, vp, vp]

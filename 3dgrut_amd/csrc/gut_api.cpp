@@ -161,7 +161,9 @@ struct gut_context {
         float beta1, beta2, eps;
         uint32_t step, block_begin, block_end;
         uint32_t extra_end;   // blocks < extra_end: waves with tiles the forward did not walk also go to the second launch
+        GutLazyMoments lazy;  // lazy moment decay of this step (d_wave_step == NULL: off)
     } early_args{};
+    bool marks_valid = false; // wave_walked holds the walked-wave marks of the cached forward for EVERY wave
     DevBuf wave_walked;       // one byte per 64-row wave (k_mark_walked_waves), valid when early_args.extra_end > 0
     int early_extra_percent = 100;
     bool stats_early = false;   // the last optimiser step used the side stream (for gut_get_stats)
@@ -307,6 +309,7 @@ float drain_timers(std::deque<EventPair>& q) {
 }  // namespace
 
 static int launch_early_part2(gut_context* h, hipStream_t s);
+gut::LazyMoments gut_make_lazy(const GutLazyMoments* lazy, uint32_t step);   // gut_train.hip
 
 extern "C" {
 
@@ -428,6 +431,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     }
     h->have_forward = false;
     h->have_backward = false;
+    h->marks_valid = false;
 
     HIP_TRY(h->tiles_count.ensure(sizeof(uint32_t) * (size_t)n));
     HIP_TRY(h->tiles_offset.ensure(sizeof(uint32_t) * (size_t)n));
@@ -725,7 +729,7 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
 int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_features, const float* d_camera_position,
                            float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
                            const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
-                           const float* d_visibility, float* d_act12_out) {
+                           const float* d_visibility, float* d_act12_out, const GutLazyMoments* lazy) {
     if (!h) return fail("gut_optimize_after_bwd: null handle");
     std::lock_guard<std::mutex> lock(h->mu);
     hipStream_t s = static_cast<hipStream_t>(stream_);
@@ -739,14 +743,29 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
         return fail("gut_optimize_after_bwd: a visibility mask cannot follow gut_optimize_rows_without_gradient");
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
+    if (lazy && d_visibility) return fail("gut_optimize_after_bwd: lazy moment decay cannot be combined with a visibility mask");
+    if (h->early_ran && ((lazy && lazy->d_wave_step) != (h->early_args.lazy.d_wave_step != nullptr)))
+        return fail("gut_optimize_after_bwd: lazy moment decay must be the same as in gut_optimize_rows_without_gradient");
     if (launch_early_part2(h, s)) return 1;  // (normally queued by gut_trace_bwd_ex already)
+    const gut::LazyMoments lz = gut_make_lazy(lazy, step);
+    // lazy moment decay: the waves that cannot receive a gradient are the same whichever kernel walks them — no tile, or no
+    // Gaussian of the wave among the entries the forward walked (unsorted variant).  The marks exist already when the side
+    // stream's second launch built them; otherwise (one-pass step) they are built here.
+    if (lz.wave_step && h->cfg.k_buffer_size == 0 && h->m && !h->marks_valid) {
+        HIP_TRY(h->wave_walked.ensure(((size_t)h->n + 63) / 64));
+        HIP_TRY(hipMemsetAsync(h->wave_walked.p, 0, ((size_t)h->n + 63) / 64, s));
+        gut::launch_mark_walked_waves(s, h->n, (uint32_t)h->tiles, h->ranges.as<uint32_t>(), h->trav_fwd.as<uint32_t>(),
+                                      (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(), h->wave_walked.as<uint8_t>());
+        h->marks_valid = true;
+    }
     const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[12] && h->kev[13];
     if (timing) (void)hipEventRecord(h->kev[12], s);
     gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, d_camera_position, h->grad16.as<float>(), h->tiles_count.as<uint32_t>(),
                                      h->feat.as<float>(), d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12, lr48, beta1, beta2,
                                      eps, step, d_visibility, d_act12_out, h->early_ran,
                                      (h->early_ran && h->early_args.extra_end) ? h->wave_walked.as<uint8_t>() : nullptr,
-                                     h->early_args.block_begin, h->early_ran ? h->early_args.extra_end : 0u);
+                                     h->early_args.block_begin, h->early_ran ? h->early_args.extra_end : 0u, lz,
+                                     (lz.wave_step && h->marks_valid) ? h->wave_walked.as<uint8_t>() : nullptr);
     HIP_TRY(hipGetLastError());
     if (timing) {
         (void)hipEventRecord(h->kev[13], s);
@@ -781,7 +800,8 @@ int gut_optimize_finish_without_gradient(gut_handle h, void* stream_) {
     gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, h->zero_word.as<float>() /* never read: no row has a colour gradient */,
                                      h->grad16.as<float>(), h->tiles_count.as<uint32_t>(), h->feat.as<float>(), ea.raw12, ea.raw_m,
                                      ea.raw_v, ea.sh48, ea.sh_m, ea.sh_v, ea.lr12, ea.lr48, ea.beta1, ea.beta2, ea.eps, ea.step, nullptr,
-                                     ea.act12, true, ea.extra_end ? h->wave_walked.as<uint8_t>() : nullptr, ea.block_begin, ea.extra_end);
+                                     ea.act12, true, ea.extra_end ? h->wave_walked.as<uint8_t>() : nullptr, ea.block_begin, ea.extra_end,
+                                     gut_make_lazy(&ea.lazy, ea.step), h->marks_valid ? h->wave_walked.as<uint8_t>() : nullptr);
     HIP_TRY(hipGetLastError());
     if (h->early_wait_pending) {
         HIP_TRY(hipStreamWaitEvent(s, h->ev_early_done, 0));
@@ -840,7 +860,7 @@ int gut_compact_gradient_rows(gut_handle h, void* stream_, const float* d_partic
 
 int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48,
                                        float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
-                                       float eps, uint32_t step, float* d_act12_out) {
+                                       float eps, uint32_t step, float* d_act12_out, const GutLazyMoments* lazy) {
     if (!h) return fail("gut_optimize_rows_without_gradient: null handle");
     std::lock_guard<std::mutex> lock(h->mu);
     hipStream_t s = static_cast<hipStream_t>(stream_);
@@ -879,7 +899,7 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     const uint32_t first = (uint32_t)((uint64_t)nblocks * (uint32_t)split_percent / 100u);
     gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), d_raw12, d_raw_m, d_raw_v, d_sh48,
                                            d_sh_m, d_sh_v, lr12, lr48, beta1, beta2, eps, step, d_act12_out, 0, first, nullptr, first, 0,
-                                           false);
+                                           false, gut_make_lazy(lazy, step));
     HIP_TRY(hipGetLastError());
     gut_context::EarlyArgs& ea = h->early_args;
     ea.raw12 = d_raw12; ea.raw_m = d_raw_m; ea.raw_v = d_raw_v; ea.sh48 = d_sh48; ea.sh_m = d_sh_m; ea.sh_v = d_sh_v;
@@ -887,6 +907,8 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     memcpy(ea.lr12, lr12, sizeof(ea.lr12));
     memcpy(ea.lr48, lr48, sizeof(ea.lr48));
     ea.beta1 = beta1; ea.beta2 = beta2; ea.eps = eps; ea.step = step; ea.block_begin = first; ea.block_end = nblocks;
+    ea.lazy = GutLazyMoments{};
+    if (lazy) ea.lazy = *lazy;
     // unsorted variant with something to walk: the second launch also takes, in the first early_extra_percent of the blocks,
     // the waves with tiles in which the forward walked no Gaussian (see launch_early_part2)
     ea.extra_end = (h->cfg.k_buffer_size == 0 && h->m) ? (uint32_t)((uint64_t)nblocks * (uint32_t)h->early_extra_percent / 100u) : 0u;
@@ -914,6 +936,7 @@ static int launch_early_part2(gut_context* h, hipStream_t s) {
         HIP_TRY(hipMemsetAsync(h->wave_walked.p, 0, ((size_t)h->n + 63) / 64, s));
         gut::launch_mark_walked_waves(s, h->n, (uint32_t)h->tiles, h->ranges.as<uint32_t>(), h->trav_fwd.as<uint32_t>(),
                                       (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(), h->wave_walked.as<uint8_t>());
+        h->marks_valid = true;
     }
     HIP_TRY(hipEventRecord(h->ev_bwd_start, s));
     HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_bwd_start, 0));
@@ -921,7 +944,8 @@ static int launch_early_part2(gut_context* h, hipStream_t s) {
     gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), ea.raw12, ea.raw_m, ea.raw_v, ea.sh48,
                                            ea.sh_m, ea.sh_v, ea.lr12, ea.lr48, ea.beta1, ea.beta2, ea.eps, ea.step, ea.act12,
                                            ea.extra_end ? 0u : ea.block_begin, ea.block_end,
-                                           ea.extra_end ? h->wave_walked.as<uint8_t>() : nullptr, ea.block_begin, ea.extra_end, true);
+                                           ea.extra_end ? h->wave_walked.as<uint8_t>() : nullptr, ea.block_begin, ea.extra_end, true,
+                                           gut_make_lazy(&ea.lazy, ea.step));
     HIP_TRY(hipGetLastError());
     const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[14] && h->kev[15];
     if (timing) {

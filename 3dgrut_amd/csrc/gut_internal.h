@@ -55,6 +55,19 @@ struct Counters {
     unsigned long long pad[3];
 };
 
+// Lazy moment decay of the fused optimiser kernels (GutLazyMoments of the C ABI + the step being applied).  A 64-row wave that
+// cannot receive a gradient in a step — no row has a tile, or the forward walked none of its Gaussians — gets its parameter
+// update from m, v READ but NOT WRITTEN BACK: wave_step[w] remembers up to which step the stored moments are current, and
+// whoever reads them next first multiplies by beta^(steps missed) from a host-made table (pow1[k] = fl(beta1^k), pow1[0] = 1).
+// Saves 472 of the 1488 bytes per row of the zero-gradient update.  wave_step == nullptr: every update writes its moments.
+struct LazyMoments {
+    uint32_t* wave_step = nullptr;
+    const float* pow1 = nullptr;
+    const float* pow2 = nullptr;
+    uint32_t len = 0;
+    uint32_t t = 0;     // the optimiser step being applied (1-based)
+};
+
 // ---- launch wrappers implemented in the .hip files -------------------------------------------------
 void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, int sh_degree,
                     const float* density12, const float* sph48, uint32_t* tiles_count, float* proj_pos,
@@ -97,7 +110,8 @@ void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const
                                  const uint32_t* tiles_count, const float* feat, float* raw12, float* raw_m, float* raw_v,
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
                                  float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only,
-                                 const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end);
+                                 const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end,
+                                 const LazyMoments& lazy, const uint8_t* rule_walked /* per-wave marks valid for EVERY wave, or null */);
 // Adam step of the rows that get no gradient this iteration (tiles_count == 0), see k_adam_rows_without_gradient
 void launch_compact_gradient_rows(hipStream_t s, uint32_t n, const float* act12, const uint32_t* tiles_count, const float* feat,
                                   float* grad16, float* records, uint32_t capacity, uint32_t* count);
@@ -105,7 +119,8 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
                                        float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* act12_out,
                                        uint32_t block_begin, uint32_t block_end /* range of 256-row blocks */,
-                                       const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end, bool second_launch);
+                                       const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end, bool second_launch,
+                                       const LazyMoments& lazy);
 void launch_count_side_stream_rows(hipStream_t s, uint32_t n, const uint32_t* tiles_count, const uint8_t* wave_walked,
                                    uint32_t split_block, uint32_t extra_end, Counters* out);
 void launch_mark_waves_with_tiles(hipStream_t s, uint32_t n, const uint32_t* tiles_count, uint8_t* wave_flags);

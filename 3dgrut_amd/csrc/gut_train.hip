@@ -117,8 +117,20 @@ __device__ __forceinline__ bool side_stream_owns_wave(const EarlyOwnership& o, b
     return o.walked && blk < o.extra_end && o.walked[wave_index] == 0;
 }
 
+// (beta1^d, beta2^d) for the moments of wave `wave`, d = optimiser steps they have missed BEFORE the one being applied;
+// (1, 1) when the moments are written every step
+__device__ __forceinline__ float2 missed_decay(const LazyMoments& lz, uint32_t wave) {
+    if (!lz.wave_step) return make_float2(1.0f, 1.0f);
+    const uint32_t seen = lz.wave_step[wave];
+    const uint32_t d = lz.t > seen ? lz.t - seen - 1u : 0u;
+    const uint32_t k = d < lz.len ? d : lz.len - 1u;   // (the trainer brings every wave up to date long before the table ends)
+    return make_float2(lz.pow1[k], lz.pow2[k]);
+}
+
 struct ShAdamParams {
     AdamParams a12, a48;
+    LazyMoments lazy;
+    const uint8_t* rule_walked;    // kScratch: per-wave "the forward walked a Gaussian of this wave" for EVERY wave, or null
     const float* cam;  // device [views,3]: sensor positions in world space
     uint32_t n, views;
     uint32_t view_stride;  // rows between consecutive views in mrgb (>= n)
@@ -177,6 +189,8 @@ __device__ __forceinline__ void adam4(const AdamParams& ap, uint32_t c0, const f
 #undef GUT_ADAM_LANE
 }
 
+__device__ __forceinline__ void scale4(float4& a, float f) { a.x *= f; a.y *= f; a.z *= f; a.w *= f; }
+
 __device__ __forceinline__ bool all_zero(const float4& m, const float4& v) {
     return m.x == 0.0f && m.y == 0.0f && m.z == 0.0f && m.w == 0.0f && v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f;
 }
@@ -219,6 +233,18 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
         return;
     // data-parallel runs: waves no rank's forward walked were updated by gut_adam_unwalked_waves (wave-uniform test)
     if (!kScratch && sp.own.walked && wave_first < sp.n && sp.own.walked[wave_first >> 6] == 0) return;
+    // lazy moment decay: a wave that cannot receive a gradient (by the rule the side-stream pass uses too, whoever processes the
+    // wave) updates its parameters from moments it does not write back; every other wave brings its moments up to date first
+    const uint32_t wave_index = wave_first >> 6;
+    bool lazy_wave = false;
+    float2 dk = make_float2(1.0f, 1.0f);
+    if (sp.lazy.wave_step && wave_first < sp.n) {
+        dk = missed_decay(sp.lazy, wave_index);
+        if (kScratch) {
+            const bool has_tiles = __ballot(i < sp.n && tiles_count[i] != 0) != 0ull;
+            lazy_wave = !has_tiles || (sp.rule_walked && sp.rule_walked[wave_index] == 0);
+        }
+    }
     float G[48];
 #pragma unroll
     for (int k = 0; k < 48; ++k) G[k] = 0.0f;
@@ -269,12 +295,16 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
             g2.x *= gs; g2.y *= gs; g2.z *= gs; g2.w = 0.0f;
             float4 ma = m12[3 * (size_t)i + 0], mb = m12[3 * (size_t)i + 1], mc = m12[3 * (size_t)i + 2];
             float4 va = v12[3 * (size_t)i + 0], vb = v12[3 * (size_t)i + 1], vc = v12[3 * (size_t)i + 2];
+            scale4(ma, dk.x); scale4(mb, dk.x); scale4(mc, dk.x);
+            scale4(va, dk.y); scale4(vb, dk.y); scale4(vc, dk.y);
             adam4(sp.a12, 0, g0, a, ma, va);
             adam4(sp.a12, 4, g1, b, mb, vb);
             adam4(sp.a12, 8, g2, c, mc, vc);
             p12[3 * (size_t)i + 0] = a; p12[3 * (size_t)i + 1] = b; p12[3 * (size_t)i + 2] = c;
-            m12[3 * (size_t)i + 0] = ma; m12[3 * (size_t)i + 1] = mb; m12[3 * (size_t)i + 2] = mc;
-            v12[3 * (size_t)i + 0] = va; v12[3 * (size_t)i + 1] = vb; v12[3 * (size_t)i + 2] = vc;
+            if (!lazy_wave) {
+                m12[3 * (size_t)i + 0] = ma; m12[3 * (size_t)i + 1] = mb; m12[3 * (size_t)i + 2] = mc;
+                v12[3 * (size_t)i + 0] = va; v12[3 * (size_t)i + 1] = vb; v12[3 * (size_t)i + 2] = vc;
+            }
             // the next forward's activated row, while the updated raw row is still in registers (saves k_activate_pack's
             // separate pass over [N,12]); rows SelectiveAdam leaves untouched keep their previous activation
             if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
@@ -324,9 +354,13 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
         const float* gsrc = wl + row * kRow + col;
         const float4 g = make_float4(gsrc[0], gsrc[1], gsrc[2], gsrc[3]);
         float4 pp = bp[q], mm = bm[q], vv = bv[q];
+        scale4(mm, dk.x); scale4(vv, dk.y);
         adam4(sp.a48, col, g, pp, mm, vv);
-        bp[q] = pp; bm[q] = mm; bv[q] = vv;
+        bp[q] = pp;
+        if (!lazy_wave) { bm[q] = mm; bv[q] = vv; }
     }
+    // the wave's stored moments are those of this step now
+    if (sp.lazy.wave_step && !lazy_wave && lane == 0 && rows_here) sp.lazy.wave_step[wave_index] = sp.lazy.t;
 }
 
 // k_adam_rows_without_gradient: the Adam step of Gaussians that cannot receive a gradient from the current view — the ones the
@@ -355,7 +389,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
                                                                           float4* __restrict__ m48, float4* __restrict__ v48,
                                                                           float4* __restrict__ act12, uint32_t block_begin,
                                                                           uint32_t block_end, EarlyOwnership own,
-                                                                          uint32_t second_launch) {
+                                                                          uint32_t second_launch, LazyMoments lazy) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_s_setprio(1);  // its few instructions issue ahead of the VALU-saturated compositor next door (+1 % step rate)
@@ -379,20 +413,30 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         //  ranks' views of the walked waves)
         const bool has_tiles = tiles_count ? (__ballot(i < n && tiles_count[i] != 0) != 0ull) : true;
         if (!side_stream_owns_wave(own, has_tiles, wave_first >> 6, blk, second_launch != 0u)) continue;
+        // lazy moment decay: the moments are brought up to date in registers and NOT written back (the wave cannot receive a
+        // gradient: its stored moments stay those of wave_step[wave], whoever reads them next decays them by the steps missed)
+        const float2 dk = missed_decay(lazy, wave_first >> 6);
+        const bool store_mv = lazy.wave_step == nullptr;
         if (mine) {
             // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
             // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
             float4 a = p12[3 * (size_t)i + 0], m = m12[3 * (size_t)i + 0], v = v12[3 * (size_t)i + 0];
+            scale4(m, dk.x); scale4(v, dk.y);
             adam4(a12, 0, zero, a, m, v);
-            p12[3 * (size_t)i + 0] = a; m12[3 * (size_t)i + 0] = m; v12[3 * (size_t)i + 0] = v;
+            p12[3 * (size_t)i + 0] = a;
+            if (store_mv) { m12[3 * (size_t)i + 0] = m; v12[3 * (size_t)i + 0] = v; }
             float4 b = p12[3 * (size_t)i + 1];
             m = m12[3 * (size_t)i + 1]; v = v12[3 * (size_t)i + 1];
+            scale4(m, dk.x); scale4(v, dk.y);
             adam4(a12, 4, zero, b, m, v);
-            p12[3 * (size_t)i + 1] = b; m12[3 * (size_t)i + 1] = m; v12[3 * (size_t)i + 1] = v;
+            p12[3 * (size_t)i + 1] = b;
+            if (store_mv) { m12[3 * (size_t)i + 1] = m; v12[3 * (size_t)i + 1] = v; }
             float4 c = p12[3 * (size_t)i + 2];
             m = m12[3 * (size_t)i + 2]; v = v12[3 * (size_t)i + 2];
+            scale4(m, dk.x); scale4(v, dk.y);
             adam4(a12, 8, zero, c, m, v);
-            p12[3 * (size_t)i + 2] = c; m12[3 * (size_t)i + 2] = m; v12[3 * (size_t)i + 2] = v;
+            p12[3 * (size_t)i + 2] = c;
+            if (store_mv) { m12[3 * (size_t)i + 2] = m; v12[3 * (size_t)i + 2] = v; }
             if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
         }
         float4* bp = p48 + (size_t)wave_first * 12;
@@ -404,8 +448,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
             if (q >= rows_here * 12u) continue;
             const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
             float4 pp = bp[q], mm = bm[q], vv = bv[q];
+            scale4(mm, dk.x); scale4(vv, dk.y);
             adam4_zero_grad(a48, s_lr48[col >> 2], pp, mm, vv);
-            bp[q] = pp; bm[q] = mm; bv[q] = vv;
+            bp[q] = pp;
+            if (store_mv) { bm[q] = mm; bv[q] = vv; }
         }
     }
 }
@@ -517,9 +563,12 @@ void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const
                                  const uint32_t* tiles_count, const float* feat, float* raw12, float* raw_m, float* raw_v,
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
                                  float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only,
-                                 const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end) {
+                                 const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end, const LazyMoments& lazy,
+                                 const uint8_t* rule_walked) {
     if (n == 0) return;
     ShAdamParams sp;
+    sp.lazy = lazy;
+    sp.rule_walked = rule_walked;
     sp.rows_with_tiles_only = rows_with_tiles_only ? 1 : 0;
     sp.own.walked = wave_walked; sp.own.split_block = split_block; sp.own.extra_end = extra_end;
     sp.clear_consumed = 0;
@@ -537,7 +586,7 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
                                        float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1,
                                        float beta2, float eps, uint32_t step, float* act12_out, uint32_t block_begin,
                                        uint32_t block_end, const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end,
-                                       bool second_launch) {
+                                       bool second_launch, const LazyMoments& lazy) {
     if (n == 0 || block_end <= block_begin) return;
     EarlyOwnership own;
     own.walked = wave_walked; own.split_block = split_block; own.extra_end = extra_end;
@@ -566,7 +615,7 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
     hipLaunchKernelGGL(k_adam_rows_without_gradient, dim3(grid), dim3(kBlock), 0, s, a12, a48, n, tiles_count,
                        reinterpret_cast<float4*>(raw12), reinterpret_cast<float4*>(raw_m), reinterpret_cast<float4*>(raw_v),
                        reinterpret_cast<float4*>(sh48), reinterpret_cast<float4*>(sh_m), reinterpret_cast<float4*>(sh_v),
-                       reinterpret_cast<float4*>(act12_out), block_begin, block_end, own, second_launch ? 1u : 0u);
+                       reinterpret_cast<float4*>(act12_out), block_begin, block_end, own, second_launch ? 1u : 0u, lazy);
 }
 
 // k_mark_walked_waves: wave_walked[id / 64] = 1 for every Gaussian id among the list entries the forward compositor walked
@@ -623,7 +672,59 @@ void launch_mark_walked_waves(hipStream_t s, uint32_t n, uint32_t tiles, const u
 }
 }  // namespace gut
 
+namespace gut {
+// k_sync_moments: brings the stored moments of every wave up to step t (m *= beta1^(t - wave_step), same for v) and marks them so:
+// what any reader would compute on the fly.  Before anything that moves rows between waves or looks at the moments from outside.
+__global__ __launch_bounds__(kBlock) void k_sync_moments(uint32_t n, float4* __restrict__ m12, float4* __restrict__ v12,
+                                                        float4* __restrict__ m48, float4* __restrict__ v48, LazyMoments lz) {
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t wave_first = wave * 64u;
+    if (wave_first >= n) return;
+    const uint32_t seen = lz.wave_step[wave];
+    if (seen >= lz.t) return;
+    const uint32_t d = lz.t - seen;
+    const uint32_t k = d < lz.len ? d : lz.len - 1u;
+    const float f1 = lz.pow1[k], f2 = lz.pow2[k];
+    const uint32_t rows_here = min(64u, n - wave_first);
+    for (uint32_t q = lane; q < rows_here * 3u; q += 64u) {
+        float4 a = m12[(size_t)wave_first * 3 + q], b = v12[(size_t)wave_first * 3 + q];
+        scale4(a, f1); scale4(b, f2);
+        m12[(size_t)wave_first * 3 + q] = a; v12[(size_t)wave_first * 3 + q] = b;
+    }
+    for (uint32_t q = lane; q < rows_here * 12u; q += 64u) {
+        float4 a = m48[(size_t)wave_first * 12 + q], b = v48[(size_t)wave_first * 12 + q];
+        scale4(a, f1); scale4(b, f2);
+        m48[(size_t)wave_first * 12 + q] = a; v48[(size_t)wave_first * 12 + q] = b;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) lz.wave_step[wave] = lz.t;
+}
+}  // namespace gut
+
+// GutLazyMoments of the C ABI + the step being applied -> the kernels' argument (NULL / no wave_step: moments written every step)
+gut::LazyMoments gut_make_lazy(const GutLazyMoments* lazy, uint32_t step) {
+    gut::LazyMoments lz;
+    if (lazy && lazy->d_wave_step && lazy->d_pow_beta1 && lazy->d_pow_beta2 && lazy->table_len >= 2 && step >= 1) {
+        lz.wave_step = lazy->d_wave_step; lz.pow1 = lazy->d_pow_beta1; lz.pow2 = lazy->d_pow_beta2; lz.len = lazy->table_len; lz.t = step;
+    }
+    return lz;
+}
+
 extern "C" {
+
+int gut_sync_moments(void* stream, uint32_t num_particles, float* d_raw_m, float* d_raw_v, float* d_sh_m, float* d_sh_v,
+                     const GutLazyMoments* lazy, uint32_t step) {
+    if (num_particles == 0) return 0;
+    if (!d_raw_m || !d_raw_v || !d_sh_m || !d_sh_v || !lazy) return 1;
+    gut::LazyMoments lz = gut_make_lazy(lazy, step ? step : 1u);
+    if (!lz.wave_step) return 3;
+    lz.t = step;   // (step 0: nothing has been applied yet, nothing to bring up to date)
+    const uint32_t waves = (num_particles + 63u) / 64u;
+    hipLaunchKernelGGL(gut::k_sync_moments, dim3((waves + 3u) / 4u), dim3(gut::kBlock), 0, static_cast<hipStream_t>(stream), num_particles,
+                       reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v), reinterpret_cast<float4*>(d_sh_m),
+                       reinterpret_cast<float4*>(d_sh_v), lz);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 int gut_activate_pack(void* stream, uint32_t num_particles, const float* d_raw12, float* d_act12) {
     if (num_particles == 0) return 0;
@@ -674,7 +775,7 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
                         float* d_mrgb, float* d_raw_grad12, float grad_scale, float* d_raw12, float* d_raw_m,
                         float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
                         float beta1, float beta2, float eps, uint32_t step, const float* d_visibility, float* d_act12_out,
-                        uint32_t mrgb_view_stride, uint32_t flags, const uint8_t* d_wave_flags) {
+                        uint32_t mrgb_view_stride, uint32_t flags, const uint8_t* d_wave_flags, const GutLazyMoments* lazy) {
     if (num_particles == 0) return 0;
     if (!d_camera_positions || !d_mrgb || !d_raw_grad12 || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v ||
         !lr12 || !lr48)
@@ -691,6 +792,9 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
     sp.own.walked = d_wave_flags; sp.own.split_block = 0; sp.own.extra_end = 0;
     sp.clear_consumed = (flags & GUT_ADAM_CLEAR_CONSUMED_GRADS) ? 1 : 0;
     if (sp.view_stride < num_particles) return 3;
+    if (lazy && d_visibility) return 3;   // a visibility mask leaves rows untouched: their moments do not decay at all
+    sp.lazy = gut_make_lazy(lazy, step);
+    sp.rule_walked = nullptr;
     hipLaunchKernelGGL(gut::k_sh_adam<false>, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
                        static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<float4*>(d_raw_grad12),
                        reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v),
@@ -706,19 +810,26 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
                      uint32_t mrgb_view_stride) {
     return gut_sh_adam_step_ex(stream, num_particles, sh_degree, num_views, d_camera_positions, const_cast<float*>(d_mrgb),
                                const_cast<float*>(d_raw_grad12), grad_scale, d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12,
-                               lr48, beta1, beta2, eps, step, d_visibility, d_act12_out, mrgb_view_stride, 0u, nullptr);
+                               lr48, beta1, beta2, eps, step, d_visibility, d_act12_out, mrgb_view_stride, 0u, nullptr, nullptr);
 }
 
-int gut_adam_unwalked_waves(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
-                            float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
-                            float beta1, float beta2, float eps, uint32_t step, float* d_act12_out) {
+int gut_adam_unwalked_waves_ex(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
+                               float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                               float beta1, float beta2, float eps, uint32_t step, float* d_act12_out, const GutLazyMoments* lazy) {
     if (num_particles == 0) return 0;
     if (!d_wave_flags || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48) return 1;
     const uint32_t nblocks = (num_particles + gut::kBlock - 1) / gut::kBlock;
     gut::launch_adam_rows_without_gradient(static_cast<hipStream_t>(stream), num_particles, nullptr, d_raw12, d_raw_m, d_raw_v, d_sh48,
                                            d_sh_m, d_sh_v, lr12, lr48, beta1, beta2, eps, step, d_act12_out, 0, nblocks, d_wave_flags,
-                                           0, nblocks, true);
+                                           0, nblocks, true, gut_make_lazy(lazy, step));
     return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int gut_adam_unwalked_waves(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
+                            float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                            float beta1, float beta2, float eps, uint32_t step, float* d_act12_out) {
+    return gut_adam_unwalked_waves_ex(stream, num_particles, d_wave_flags, d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12, lr48,
+                                      beta1, beta2, eps, step, d_act12_out, nullptr);
 }
 
 int gut_scatter_gradient_records(void* stream, const float* d_records, uint32_t count, uint32_t num_particles, float* d_raw_grad12,

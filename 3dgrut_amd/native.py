@@ -126,7 +126,7 @@ class NativeTrainStep:
     def __init__(self, model: NativeGaussianModel, tracer: Tracer, scene_extent=1.0, world_size=1, selective=False,
                  betas=(0.9, 0.999), eps=1e-15, fused_sh_adam=True, rank=0, fused_loss=True, lambda_l1=0.8, lambda_ssim=0.2,
                  dp_chunks=4, dp_chunk_min_rows=1 << 20, fuse_epilogue=True, schedule=None,
-                 overlap_optimizer=None, dp_exchange="sparse", dp_side_stream=True):
+                 overlap_optimizer=None, dp_exchange="sparse", dp_side_stream=True, lazy_moments=True):
         self.model = model
         self.tracer = tracer
         self.raster: SplatRaster = tracer.tracer_wrapper
@@ -153,6 +153,17 @@ class NativeTrainStep:
         z = lambda c: torch.zeros((n, c), dtype=torch.float32, device=dev)
         self.m12, self.v12, self.m48, self.v48 = z(12), z(12), z(48), z(48)
         self.fused = bool(fused_sh_adam)
+        # Lazy moment decay (gut_hip.h: GutLazyMoments): a wave that cannot receive a gradient in a step updates its parameters
+        # from moments it reads but does not write back; `wave_step[w]` holds the step up to which wave w's stored moments are
+        # current and the next reader multiplies by beta^(steps missed).  m12 / v12 / m48 / v48 are therefore only current
+        # after sync_moments().  Off with SelectiveAdam (no decay at all there) and with the unfused optimiser.
+        self.lazy_moments = bool(lazy_moments) and self.fused and not selective
+        self.LAZY_TABLE = 1024
+        k = np.arange(self.LAZY_TABLE, dtype=np.float64)
+        self._pow1 = torch.as_tensor((float(betas[0]) ** k).astype(np.float32), device=dev)
+        self._pow2 = torch.as_tensor((float(betas[1]) ** k).astype(np.float32), device=dev)
+        self.wave_step = None
+        self.step_id = 0
         self.fused_loss = bool(fused_loss)
         self.fuse_epilogue = bool(fuse_epilogue)
         # one view, fused epilogue: the Adam step of the 64-row waves that cannot receive a gradient from the view (no tile, or
@@ -199,7 +210,6 @@ class NativeTrainStep:
         self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
         self.row_listeners = []         # callables(perm): told when reorder() re-sorts the rows (strategy statistics follow)
         self.resize_workspace()
-        self.step_id = 0
         self.phase_timing = False   # record HIP events around the phases of step() (bench / profiling)
         self._phase_events = []
 
@@ -208,6 +218,9 @@ class NativeTrainStep:
         n = self.model.num_gaussians
         dev = self.model.raw.device
         self._act_key = None
+        if getattr(self, "lazy_moments", False):
+            # (whoever changed the rows brought the moments up to date first: sync_moments)
+            self.wave_step = torch.full(((n + 63) // 64,), int(getattr(self, "step_id", 0)), dtype=torch.int32, device=dev)
         self.act = torch.empty((n, 12), dtype=torch.float32, device=dev)
         self.g12 = torch.empty((n, 12), dtype=torch.float32, device=dev)
         if self.fused:
@@ -241,8 +254,28 @@ class NativeTrainStep:
         else:
             self.g48 = torch.empty((n, 48), dtype=torch.float32, device=dev)
 
+    def _lazy(self):
+        """GutLazyMoments for the optimiser entry points, or None."""
+        if not self.lazy_moments or self.wave_step is None:
+            return None
+        return _capi.GutLazyMoments(self.wave_step.data_ptr(), self._pow1.data_ptr(), self._pow2.data_ptr(), self.LAZY_TABLE)
+
+    def sync_moments(self):
+        """Bring every stored Adam moment up to the last step applied (gut_sync_moments).  Call before reading m12 / v12 / m48 /
+        v48, and before anything that moves rows between 64-row waves (reorder and the strategy's row surgery do)."""
+        lz = self._lazy()
+        if lz is None or self.model.num_gaussians == 0:
+            return
+        st = torch.cuda.current_stream(self.model.raw.device).cuda_stream
+        with torch.cuda.device(self.model.raw.device):
+            rc = self._lib.gut_sync_moments(C.c_void_p(st), self.model.num_gaussians, self.m12.data_ptr(), self.v12.data_ptr(),
+                                            self.m48.data_ptr(), self.v48.data_ptr(), C.byref(lz), int(self.step_id))
+        if rc:
+            raise RuntimeError(f"[3dgut] sync_moments failed ({rc})")
+
     def reorder(self, perm: torch.Tensor):
         """Apply a row permutation to the parameters and the optimiser state (new row i = old row perm[i])."""
+        self.sync_moments()
         m = self.model
         perm = perm.to(m.raw.device)
         m.raw = m.raw[perm].contiguous()
@@ -402,11 +435,14 @@ class NativeTrainStep:
             # The side-stream optimiser pass may already be running for this iteration (it is queued right behind the forward):
             # finish the step for every other row with a zero gradient instead of leaving the parameters half advanced and the
             # handle refusing the next forward (gut_optimize_finish_without_gradient); then let the error through.
-            try:
-                self.raster.finish_optimizer_step_without_gradient()
-                self._act_key = None
-            except Exception:
-                pass
+            if getattr(self, "_early_queued", False):
+                self._early_queued = False
+                try:
+                    self.raster.finish_optimizer_step_without_gradient()
+                    self._act_key = None
+                    self.step_id += 1   # the iteration WAS applied: every row took its step, with a zero gradient
+                except Exception:
+                    pass
             raise
 
     def _step(self, batch):
@@ -433,7 +469,8 @@ class NativeTrainStep:
         rgba, dist_, hits, vis = self.forward(batch)
         if early:
             self.raster.optimize_rows_without_gradient(m.raw, self.m12, self.v12, m.features, self.m48, self.v48, self.lr12,
-                                                       self.lr48, self.betas, self.eps, self.step_id + 1, self.act)
+                                                       self.lr48, self.betas, self.eps, self.step_id + 1, self.act, lazy=self._lazy())
+            self._early_queued = True
         self._mark(evs)
         gt = batch.rgb_gt
         if self.fused_loss and m.background_color in ("black", "white") and gt.dtype == torch.float32 and gt.is_contiguous() \
@@ -480,7 +517,7 @@ class NativeTrainStep:
                 vmask = vis.reshape(-1) if self.selective else None
                 self.raster.optimize_after_bwd(m.n_active_features, self._sensor_position(batch), m.raw, self.m12, self.v12, m.features,
                                                self.m48, self.v48, self.lr12, self.lr48, self.betas, self.eps,
-                                               0 if self.selective else self.step_id + 1, vmask, self.act)
+                                               0 if self.selective else self.step_id + 1, vmask, self.act, lazy=self._lazy())
                 self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
                 self._mark(evs)
                 self._end_of_step(evs)
@@ -517,13 +554,17 @@ class NativeTrainStep:
                 if works:
                     works[k][0].wait()
                     works[k][1].wait()
-                rc = self._lib.gut_sh_adam_step(
+                lz = self._lazy()
+                if lz is not None:   # chunks are multiples of 256 rows: whole waves
+                    lz = _capi.GutLazyMoments(self.wave_step.data_ptr() + 4 * (r0 // 64), self._pow1.data_ptr(), self._pow2.data_ptr(), self.LAZY_TABLE)
+                rc = self._lib.gut_sh_adam_step_ex(
                     C.c_void_p(st), r1 - r0, m.n_active_features, w, self.cams.data_ptr(), gathered.data_ptr(),
                     self.g12.data_ptr() + 48 * r0, 1.0 / w, m.raw.data_ptr() + 48 * r0, self.m12.data_ptr() + 48 * r0,
                     self.v12.data_ptr() + 48 * r0, m.features.data_ptr() + 192 * r0, self.m48.data_ptr() + 192 * r0,
                     self.v48.data_ptr() + 192 * r0, self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p),
                     self.betas[0], self.betas[1], self.eps, 0 if self.selective else self.step_id + 1,
-                    None if vmask is None else vmask.data_ptr() + 4 * r0, self.act.data_ptr() + 48 * r0, r1 - r0)
+                    None if vmask is None else vmask.data_ptr() + 4 * r0, self.act.data_ptr() + 48 * r0, r1 - r0, 0, None,
+                    None if lz is None else C.byref(lz))
                 if rc:
                     raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
             # any in-place torch edit of raw (densification, MCMC noise, ...) bumps _version and forces a fresh activation
@@ -566,11 +607,12 @@ class NativeTrainStep:
             with torch.cuda.stream(self._side):
                 if flags_work is not None:
                     flags_work.wait()
-                rc = self._lib.gut_adam_unwalked_waves(
+                lz = self._lazy()
+                rc = self._lib.gut_adam_unwalked_waves_ex(
                     C.c_void_p(self._side.cuda_stream), n, self.wave_flags.data_ptr(), m.raw.data_ptr(), self.m12.data_ptr(),
                     self.v12.data_ptr(), m.features.data_ptr(), self.m48.data_ptr(), self.v48.data_ptr(),
                     self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p), self.betas[0], self.betas[1], self.eps,
-                    self.step_id + 1, self.act.data_ptr())
+                    self.step_id + 1, self.act.data_ptr(), None if lz is None else C.byref(lz))
                 if rc:
                     raise RuntimeError(f"[3dgut] adam_unwalked_waves failed ({rc})")
             if flags_work is not None:
@@ -622,7 +664,8 @@ class NativeTrainStep:
             m.raw.data_ptr(), self.m12.data_ptr(), self.v12.data_ptr(), m.features.data_ptr(), self.m48.data_ptr(),
             self.v48.data_ptr(), self.lr12.ctypes.data_as(f32p), self.lr48.ctypes.data_as(f32p), self.betas[0], self.betas[1],
             self.eps, 0 if self.selective else self.step_id + 1, None if vmask is None else vmask.data_ptr(), self.act.data_ptr(),
-            n, _capi.ADAM_CLEAR_CONSUMED_GRADS, self.wave_flags.data_ptr() if side_on else None)
+            n, _capi.ADAM_CLEAR_CONSUMED_GRADS, self.wave_flags.data_ptr() if side_on else None,
+            None if self._lazy() is None else C.byref(self._lazy()))
         if rc:
             raise RuntimeError(f"[3dgut] sh_adam_step failed ({rc})")
         if side_on:
@@ -630,6 +673,7 @@ class NativeTrainStep:
         self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])
 
     def _end_of_step(self, evs):
+        self._early_queued = False
         if self.world_size > 1 and self.replica_check_every and self.step_id % self.replica_check_every == 0:
             assert_replicas_identical([self.model.raw, self.model.features, self.m12, self.v12, self.m48, self.v48], self.world_size,
                                       what=f"after step {self.step_id}")
@@ -643,6 +687,8 @@ class NativeTrainStep:
             self.lr12[0:3] = lr         # passed by value to the optimiser kernels of the next step
             self.model.n_active_features = deg
         self.step_id += 1
+        if self.lazy_moments and self.step_id % (self.LAZY_TABLE // 2) == 0:
+            self.sync_moments()   # long before any wave's missed steps run off the end of the beta^k tables
 
     def render(self, batch, train=False):
         return self.tracer.render(self.model, batch, train=train, frame_id=self.step_id)

@@ -55,8 +55,14 @@ class _StateOps:
     def n(self):
         return self.m.raw.shape[0]
 
+    def _sync(self):
+        sync = getattr(self.s, "sync_moments", None)   # lazily decayed moments are brought up to date before rows move between waves
+        if sync is not None:
+            sync()
+
     def _apply(self, fn_param, fn_moment):
         s, m = self.s, self.m
+        self._sync()
         m.raw = fn_param(m.raw)
         m.features = fn_param(m.features)
         s.m12, s.v12 = fn_moment(s.m12), fn_moment(s.v12)
@@ -71,6 +77,7 @@ class _StateOps:
 
     def append(self, raw_new, feat_new):
         s, m = self.s, self.m
+        self._sync()
         k = raw_new.shape[0]
         m.raw = torch.cat([m.raw, raw_new]).contiguous()
         m.features = torch.cat([m.features, feat_new]).contiguous()

@@ -271,7 +271,7 @@ class SplatRaster:
         return dens_g, sph_g
 
     def optimize_after_bwd(self, num_active_features, camera_position, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps,
-                           step, visibility=None, act_out=None):
+                           step, visibility=None, act_out=None, lazy=None):
         """Per-Gaussian backward epilogue + SH-gradient rebuild + Adam in one pass (gut_optimize_after_bwd); follows a
         trace_bwd(..., skip_epilogue=True) on the same stream.  lr12 / lr48: float32 numpy arrays."""
         f32p = C.POINTER(C.c_float)
@@ -281,10 +281,10 @@ class SplatRaster:
                                                   raw12.data_ptr(), raw_m.data_ptr(), raw_v.data_ptr(), sh48.data_ptr(), sh_m.data_ptr(),
                                                   sh_v.data_ptr(), lr12.ctypes.data_as(f32p), lr48.ctypes.data_as(f32p), betas[0],
                                                   betas[1], eps, int(step), None if visibility is None else visibility.data_ptr(),
-                                                  None if act_out is None else act_out.data_ptr())
+                                                  None if act_out is None else act_out.data_ptr(), None if lazy is None else C.byref(lazy))
         _capi.check(rc, "optimize_after_bwd")
 
-    def optimize_rows_without_gradient(self, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps, step, act_out=None):
+    def optimize_rows_without_gradient(self, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps, step, act_out=None, lazy=None):
         """Adam step of the rows the projection gave no tile, on the handle's low-priority side stream, between trace and
         trace_bwd(..., skip_epilogue=True) (gut_optimize_rows_without_gradient); optimize_after_bwd must follow."""
         f32p = C.POINTER(C.c_float)
@@ -293,7 +293,7 @@ class SplatRaster:
             rc = self._lib.gut_optimize_rows_without_gradient(
                 self._handle, C.c_void_p(stream), raw12.data_ptr(), raw_m.data_ptr(), raw_v.data_ptr(), sh48.data_ptr(),
                 sh_m.data_ptr(), sh_v.data_ptr(), lr12.ctypes.data_as(f32p), lr48.ctypes.data_as(f32p), betas[0], betas[1], eps,
-                int(step), None if act_out is None else act_out.data_ptr())
+                int(step), None if act_out is None else act_out.data_ptr(), None if lazy is None else C.byref(lazy))
         _capi.check(rc, "optimize_rows_without_gradient")
 
     def finish_optimizer_step_without_gradient(self):

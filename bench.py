@@ -51,7 +51,9 @@ VALU_ISSUE_NS = 1.16   # one wave64 VALU instruction per SIMD every 1.16 ns with
 
 
 def algorithmic_bytes(st, kernel, end_bit):
-    """SURVEY.md §8d byte model, per kernel launch."""
+    """SURVEY.md §8d byte model, per kernel launch.  st["lazy_moments"]: the zero-gradient update of a wave that cannot receive a
+    gradient reads p, m, v (720 B per row) and writes p and the next activation only (240 + 48 B): 1008 instead of 1488 B."""
+    Z = 1008 if st.get("lazy_moments") else 1488
     N, V, M, T, P = (st[k] for k in ("num_particles", "num_visible", "num_intersections", "num_tiles", "num_pixels"))
     Ef, Eb = st["traversed_fwd"], st["traversed_bwd"]
     b = math.ceil((end_bit - 32) / 8)  # lazy tile order (default): onesweep passes over the tile bits only (csrc/gut_sort.hip)
@@ -67,15 +69,17 @@ def algorithmic_bytes(st, kernel, end_bit):
         # one-pass optimiser (k_sh_adam<scratch>): raw p/m/v in+out 288, next activation 48, SH p/m/v in+out 1152, count 4 per
         # Gaussian; 64-byte gradient row read, 12-byte RGB, and the 64-byte row zeroed again (replaces the per-step clear of the
         # whole gradient buffer) per Gaussian with tiles
+        # (one-pass form with lazy moments: the rows of gradient-free waves, counted by the library as side_stream_rows when the
+        #  side stream ran, move Z instead of 1488 bytes; without that count the figure is the eager upper bound)
         "optimizer": 1492 * N + (76 + 64) * V,
         # split form (default at one view): R = st["side_stream_rows"] rows (whole 64-row waves: those without any tile, and part
         # of those the forward walked no Gaussian of; counted by the library for the last step) are updated by
         # k_adam_rows_without_gradient on a side stream under the compositing kernels, k_sh_adam then walks the other N - R rows
         # (at most V of them have a gradient row); both read every tile count (4 N)
         "optimizer_late": 4 * N + 1488 * (N - (st.get("side_stream_rows") or (N - V))) + (76 + 64) * min(V, N - (st.get("side_stream_rows") or (N - V))),
-        "optimizer_early": 4 * N + 1488 * (st.get("side_stream_rows") or (N - V)),
+        "optimizer_early": 4 * N + Z * (st.get("side_stream_rows") or (N - V)),
         # its second launch alone: walks every row block once the forward's walked set is known (tile counts + one byte per wave)
-        "optimizer_early_2": 4 * N + N // 64 + 1488 * max(0, (st.get("side_stream_rows") or 0) - (st.get("side_stream_rows_first_launch") or 0)),
+        "optimizer_early_2": 4 * N + N // 64 + Z * max(0, (st.get("side_stream_rows") or 0) - (st.get("side_stream_rows_first_launch") or 0)),
     }[kernel]
 
 
@@ -131,7 +135,10 @@ def cpu_baseline_per_ray_torch(scene, cams_mod, pose_mod, W, H, fx, c2w, sh_degr
     centred crop; the Gaussian set is culled with the UT projection rule to the ones whose 2-D extent touches the
     crop (otherwise brute force over all 6 M).  The crop doubles until ~budget_s of CPU work is reached."""
     prt = importlib.import_module("oracle.per_ray_torch")
-    threads = max(1, os.cpu_count() or 1)   # every host core (BASELINE.md §3)
+    # 32 threads, not every core: the composite is a chain of small per-chunk tensor ops (1024 rays x 1024 Gaussians), and torch's
+    # CPU kernels get SLOWER beyond a few dozen threads on them — measured on a 256-thread GPU box: 13 s for a 4x4 crop with 256
+    # threads (1.2e-6 images/s) against 14 s for a 128x128 crop with 32 (1.1e-3 images/s)
+    threads = max(1, min(os.cpu_count() or 1, 32))
     torch.set_num_threads(threads)
     tq = pose_mod.sensor_pose_from_c2w(c2w).T_world_sensors[0]
     cam = dict(model="pinhole", principal_point=[W / 2, H / 2], focal_length=[fx, fx])
@@ -286,7 +293,8 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
         stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
                                              rank=rank, fused_sh_adam=not args.dense_exchange,
                                              overlap_optimizer=False if args.no_overlap_optimizer else None,
-                                             dp_exchange=args.dp_exchange, dp_side_stream=not args.no_dp_side_stream)
+                                             dp_exchange=args.dp_exchange, dp_side_stream=not args.no_dp_side_stream,
+                                             lazy_moments=not getattr(args, "no_lazy_moments", False))
         if not getattr(args, "fresh_optimizer_state", False):
             # Synthetic MID-TRAINING optimiser state, like the synthetic parameters: every row has non-zero Adam moments, as every
             # Gaussian of a trained 6 M scene has (a moment only returns to exact zero after thousands of gradient-free steps),
@@ -364,6 +372,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     ktimes, kcount = raster.kernel_times_mean()
     fb = raster.collect_times()
     stats = raster.stats()
+    stats["lazy_moments"] = bool(getattr(stepper, "lazy_moments", False))
 
     # forward-only render time (reference's FPS definition: mean forward_render ms, threedgrut/render.py:231-251)
     with torch.no_grad():
@@ -449,6 +458,9 @@ def main():
     ap.add_argument("--colmap-downsample", type=int, default=1, help="images_<N>/ and intrinsics / N (MipNeRF360 runs use 4 for bicycle)")
     ap.add_argument("--no-drop-in", action="store_true",
                     help="skip the short second measurement through the reference's own surface (Tracer.render -> _Autograd -> torch.optim.Adam)")
+    ap.add_argument("--no-lazy-moments", action="store_true",
+                    help="write both Adam moments of every row every step (default: waves that cannot receive a gradient read their moments, "
+                         "bring them up to date in registers and do not write them back; gut_hip.h: GutLazyMoments)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
                     help="one optimiser kernel after the backward instead of the side-stream pass for the waves that cannot receive a gradient")
     args = ap.parse_args()
@@ -580,6 +592,7 @@ def main():
                        "storage_order": ("morton" if (args.trainer == "native" and not args.scene_order) else "as generated"),
                        "placement_trials_ms": [round(t, 3) for t in getattr(stepper, "placement_trials_ms", [])] or None,
                        "optimizer_overlap": bool(getattr(stepper, "overlap_optimizer", False)),
+                       "lazy_moment_decay": bool(getattr(stepper, "lazy_moments", False)),
                        "optimizer_overlap_probe_ms": ({k: round(v, 3) for k, v in stepper._overlap_probe.items() if k in ("ms_on", "ms_off")}
                                                       if getattr(stepper, "_overlap_probe", None) else None)},
             "render_ms_per_frame": res["render_ms"],

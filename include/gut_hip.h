@@ -29,8 +29,8 @@ extern "C" {
 #endif
 
 /* Bumped on every change of a struct layout, an array length or an entry point's signature (2: GutStats grew to 80 bytes and
- * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: gut_optimize_finish_without_gradient, gut_trace_fields / gut_trace_bwd_fields,
- * the tile partition replaces the radix passes behind GUT_BUF_*). */
+ * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: GutLazyMoments in the gut_optimize_* / gut_sh_adam_step_ex signatures, gut_sync_moments,
+ * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev). */
 #define GUT_ABI_VERSION 3
 
 typedef struct gut_context* gut_handle;
@@ -252,6 +252,28 @@ int gut_adam_step(void* stream, uint64_t rows, uint32_t cols, float* d_param, co
                   float* d_exp_avg_sq, const float* lr_per_col, float beta1, float beta2, float eps, uint32_t step,
                   const float* d_visibility);
 
+/* ---- Lazy moment decay of the fused optimiser entry points (gut_optimize_*, gut_adam_unwalked_waves_ex, gut_sh_adam_step_ex) ----
+ * Adam with a zero gradient still decays both moments of every parameter (torch.optim.Adam semantics), i.e. reads AND writes
+ * 2 x 236 bytes per Gaussian per step for nothing but two multiplications by constants.  With a GutLazyMoments the zero-gradient
+ * update of a 64-row wave that cannot receive a gradient in this step — no row of it has a tile, or the forward compositor walked
+ * none of its Gaussians (the backward is bounded by the forward's per-tile depth) — READS the moments, brings them up to date in
+ * registers, updates the parameters, and does NOT write the moments back: d_wave_step[w] (one uint32 per wave, caller-owned,
+ * zero-initialised) holds the step up to which the stored moments of wave w are current, and the next kernel that reads them
+ * multiplies by beta^(steps missed), taken from the caller's tables d_pow_beta1/2[k] = (float) beta^k, k < table_len
+ * (d_pow[0] = 1).  Every wave that can receive a gradient is brought up to date, updated and written as before.  The rule
+ * does not depend on which kernel walks a wave, so one-pass and two-pass steps stay bit-identical.  The result differs from
+ * writing the moments every step only by the rounding of beta^k against k successive multiplications (~1e-7 relative).
+ * gut_sync_moments brings every stored moment up to `step` (call it before moving rows between waves, reading the moments
+ * from outside, or every table_len / 2 steps).  Not available with a visibility mask (SelectiveAdam does not decay at all). */
+typedef struct GutLazyMoments {
+    uint32_t* d_wave_step;       /* [ceil(N / 64)] */
+    const float* d_pow_beta1;    /* [table_len] */
+    const float* d_pow_beta2;    /* [table_len] */
+    uint32_t table_len;
+} GutLazyMoments;
+int gut_sync_moments(void* stream, uint32_t num_particles, float* d_raw_m, float* d_raw_v, float* d_sh_m, float* d_sh_v,
+                     const GutLazyMoments* lazy, uint32_t step /* the last optimiser step applied */);
+
 /* Fused "SH gradient + Adam" step of the native trainer.  For every Gaussian: Adam on the raw [N,12] row with
  * d_raw_grad12 (already summed over views), then the [N,48] SH row with the gradient
  *     sum_v Y_k(normalize(pos - camera_position[v])) * mrgb[v][i][c]   (k < (sh_degree+1)^2, else 0)
@@ -278,7 +300,7 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
 int gut_optimize_after_bwd(gut_handle h, void* stream, int32_t num_active_features, const float* d_camera_position,
                            float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
                            const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
-                           const float* d_visibility, float* d_act12_out);
+                           const float* d_visibility, float* d_act12_out, const GutLazyMoments* lazy /* may be NULL */);
 
 /* Optional first half of that optimiser step, to be called BETWEEN gut_trace and gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) on
  * the forward's stream.  Gaussians that cannot receive a gradient from this view get their Adam step (same arithmetic as
@@ -296,7 +318,8 @@ int gut_optimize_after_bwd(gut_handle h, void* stream, int32_t num_active_featur
  * parameter tensors on other streams between the two calls. */
 int gut_optimize_rows_without_gradient(gut_handle h, void* stream, float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48,
                                        float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1,
-                                       float beta2, float eps, uint32_t step, float* d_act12_out);
+                                       float beta2, float eps, uint32_t step, float* d_act12_out,
+                                       const GutLazyMoments* lazy /* may be NULL; must match gut_optimize_after_bwd's */);
 
 /* Ends an optimiser step that gut_optimize_rows_without_gradient began but gut_optimize_after_bwd cannot finish (the caller's
  * loss raised, the backward was rejected, ...): every wave the side stream does not own takes the same Adam step with an
@@ -338,7 +361,8 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
                         float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,
                         const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
                         const float* d_visibility, float* d_act12_out, uint32_t mrgb_view_stride, uint32_t flags,
-                        const uint8_t* d_wave_flags /* may be NULL; else waves with flag 0 are left alone, see below */);
+                        const uint8_t* d_wave_flags /* may be NULL; else waves with flag 0 are left alone, see below */,
+                        const GutLazyMoments* lazy /* may be NULL */);
 
 /* Data-parallel form of the side-stream optimiser pass (single-view form: gut_optimize_rows_without_gradient).
  * gut_mark_walked_waves: after gut_trace, same stream: d_wave_flags [ceil(N/64)] bytes := 1 for every 64-row wave that holds a
@@ -354,6 +378,10 @@ int gut_mark_walked_waves(gut_handle h, void* stream, uint8_t* d_wave_flags);
 int gut_adam_unwalked_waves(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
                             float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
                             float beta1, float beta2, float eps, uint32_t step, float* d_act12_out);
+/* ... with lazy moment decay (NULL = as above) */
+int gut_adam_unwalked_waves_ex(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
+                               float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
+                               float beta1, float beta2, float eps, uint32_t step, float* d_act12_out, const GutLazyMoments* lazy);
 
 /* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */

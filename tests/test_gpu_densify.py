@@ -130,6 +130,7 @@ def test_densification_on_the_live_trainer():
         if step == 6:             # make sure the prune has something to remove, and that N ends ragged
             with torch.no_grad():
                 st.model.raw[torch.arange(0, st.model.num_gaussians, 9, device=DEV), 3] = -9.0
+        st.sync_moments()   # the stored moments are decayed lazily: bring them up to date before looking at them
         before = {k: v.clone().cpu() for k, v in _state(st).items()}
         n_before = st.model.num_gaussians
         if gs.post_optimizer_step(step, EXTENT):
@@ -164,6 +165,7 @@ def test_densification_on_the_live_trainer():
         for name, t in _state(ref).items():
             t.copy_(_state(st)[name])
         ref.step_id = st.step_id
+        ref.wave_step.copy_(st.wave_step)   # which step each wave's stored moments belong to travels with them
         b = _batch(views[k], gts[k])
         ref.step(b); st.step(b)
         torch.cuda.synchronize()

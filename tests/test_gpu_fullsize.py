@@ -271,7 +271,14 @@ def test_side_stream_optimiser_at_full_size_in_spatial_order():
                 assert float(differs.float().mean()) < 2e-3, f"step {k}: {name}: {float(differs.float().mean())} of the elements differ"
         # and they did move (zero-gradient Adam step on non-zero moments), i.e. the comparison above is not vacuous
         assert float((state(ovl)["raw"][exact] - before["raw"][exact]).abs().max()) > 0
-        assert float((state(ovl)["m48"][exact] - before["m48"][exact]).abs().max()) > 0
+        # lazy moment decay: the stored moments of those waves are NOT rewritten (they are brought up to date in registers) ...
+        assert torch.equal(state(ovl)["m48"][exact], before["m48"][exact]) and ovl.lazy_moments
+        last_exact, last_before = exact, before
+    # ... until something asks for them: both forms then hold the same, decayed, moments
+    ref.sync_moments(); ovl.sync_moments()
+    assert torch.equal(ref.m48[last_exact], ovl.m48[last_exact]) and torch.equal(ref.v12[last_exact], ovl.v12[last_exact])
+    assert float((ovl.m48[last_exact] - last_before["m48"][last_exact]).abs().max()) > 0
+    assert int(ovl.wave_step.min()) == ovl.step_id == 3
     kt = ovl.raster.kernel_times()
     assert kt["optimizer_early"] > 0 and kt["optimizer_early_2"] > 0 and kt["optimizer"] > 0
 

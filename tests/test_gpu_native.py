@@ -445,6 +445,7 @@ def test_a_failing_step_is_finished_with_a_zero_gradient():
     view = make_view("pinhole", 96, 64, cams.look_at_c2w((0.1, 0, -3.5), (0, 0, 0)), fx=90.0)
     good = to_batch(view, DEV); good.rgb_gt = torch.rand((1, 64, 96, 3), generator=torch.Generator().manual_seed(2)).to(DEV)
     ovl.step(good); ovl.step(good)                       # non-trivial moments
+    ovl.sync_moments()                                   # (lazily decayed moments: bring the stored ones up to date before cloning them)
     n = ovl.model.num_gaussians
     state = lambda st: dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v12=st.v12, m48=st.m48, v48=st.v48)
     exp = {k: v.clone() for k, v in state(ovl).items()}
@@ -459,6 +460,8 @@ def test_a_failing_step_is_finished_with_a_zero_gradient():
     bad = to_batch(view, DEV); bad.rgb_gt = "not a tensor"
     with pytest.raises(AttributeError):
         ovl.step(bad)
+    assert ovl.step_id == 3                              # the iteration WAS applied (with a zero gradient), although step() raised
+    ovl.sync_moments()
     torch.cuda.synchronize()
     for k, v in state(ovl).items():
         assert torch.equal(v, exp[k]), k
@@ -478,6 +481,60 @@ def test_a_failing_step_is_finished_with_a_zero_gradient():
                              rgba, torch.zeros_like(rgba), dist_, None)
     ovl.raster.finish_optimizer_step_without_gradient()
     ovl.forward(good)
+
+
+def test_lazy_moment_decay_equals_writing_the_moments_every_step():
+    """GutLazyMoments: waves that cannot receive a gradient read their moments, bring them up to date in registers and do not write
+    them back; the next reader multiplies by beta^(steps missed).  Against the same trainer writing both moments every step
+    (lazy_moments=False = torch.optim.Adam's schedule of roundings), over eight steps on changing views, from non-zero moments on
+    every row: rows no view ever touched — no float-atomic noise, so a clean comparison — agree to the rounding of beta^k against k
+    successive multiplications; the stored moments really are stale in between and current after sync_moments()."""
+    sc = scenes.scene_c1(20000, 23)
+    W, H = 160, 120
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(5)).to(DEV)
+    dirs = [(1, 0, 0), (-1, 0.2, 0), (0, 1, 0.1), (1, 0.1, 0), (0.1, -1, 0), (0, 0.1, 1), (1, 0, 0.1), (-1, 0.2, 0)]
+    views = [make_view("pinhole", W, H, cams.look_at_c2w((0.05 * k, 0.0, 0.02 * k), d), fx=140.0) for k, d in enumerate(dirs)]
+    steppers = {}
+    for lazy in (False, True):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+        st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, overlap_optimizer=True, lazy_moments=lazy)
+        g = torch.Generator(device=DEV).manual_seed(7)
+        for m_, v_ in ((st.m12, st.v12), (st.m48, st.v48)):
+            m_.normal_(0.0, 1e-4, generator=g)
+            v_.fill_(1e-6)
+        steppers[lazy] = st
+    eager, lazy = steppers[False], steppers[True]
+    assert lazy.lazy_moments and not eager.lazy_moments and eager.wave_step is None
+    m48_0 = lazy.m48.clone()
+    touched = torch.zeros(20000, dtype=torch.bool, device=DEV)
+    stale_seen = 0
+    for k, view in enumerate(views):
+        for st in (eager, lazy):
+            b = to_batch(view, DEV); b.T_to_world = b.T_to_world.cpu(); b.rgb_gt = gt
+            st.step(b)
+        cnt = lazy.raster.debug_buffer("tiles_count")
+        assert torch.equal(cnt, eager.raster.debug_buffer("tiles_count"))
+        owned = exact_wave_mask(cnt, _rows_in_unwalked_waves(lazy.raster, 20000))
+        touched |= ~owned
+        # a wave that has not been able to receive a gradient so far still holds its INITIAL moments, k + 1 steps stale
+        never = ~touched
+        assert torch.equal(lazy.m48[never], m48_0[never])
+        stale_seen = max(stale_seen, int(lazy.step_id - lazy.wave_step.min()))
+    assert stale_seen == len(views) and int(never.sum()) > 2000
+    lazy.sync_moments()
+    assert int(lazy.wave_step.min()) == lazy.step_id == len(views)
+    for name in ("m12", "v12", "m48", "v48"):
+        a, b = getattr(eager, name)[never], getattr(lazy, name)[never]
+        assert torch.allclose(a, b, rtol=2e-6, atol=0.0), name              # beta^8 in one rounding vs eight
+        assert not torch.equal(b, dict(m48=m48_0[never]).get(name, b + 1))    # ... and they did decay
+    for name, t in (("raw", lazy.model.raw), ("features", lazy.model.features), ("act", lazy.act)):
+        r = dict(raw=eager.model.raw, features=eager.model.features, act=eager.act)[name]
+        assert torch.allclose(r[never], t[never], rtol=1e-6, atol=1e-7), name
+        assert float((r[~never] - t[~never]).abs().max()) < 0.2              # (rows with gradients: float-atomic noise through Adam)
+    # sync is idempotent and invisible to the next step: two more steps, one of them right after a sync
+    snap = {k: getattr(lazy, k).clone() for k in ("m12", "v12", "m48", "v48")}
+    lazy.sync_moments()
+    assert all(torch.equal(getattr(lazy, k), v) for k, v in snap.items())
 
 
 def test_spatial_storage_order_is_transparent():
