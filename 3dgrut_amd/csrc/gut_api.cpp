@@ -134,6 +134,8 @@ struct gut_context {
 
     // per-N scratch
     DevBuf tiles_count, tiles_offset, proj_pos, conic_opacity, extent, depth, feat, grad16, scan_temp;
+    DevBuf packed12;   // gut_trace_fields: the [N,12] rows packed from the caller's four tensors (kept for its backward)
+    bool packed_valid = false;
     // per-M scratch
     DevBuf keys_unsorted, keys_sorted, ids_unsorted, ids_sorted, sort_temp;
     // lazy per-tile depth order (unsorted variant): keys_sorted / ids_sorted are grouped by tile only, the forward compositor
@@ -384,7 +386,7 @@ void gut_destroy(gut_handle h) {
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
                       &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters, &h->ids_ordered,
-                      &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered, &h->wave_walked};
+                      &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered, &h->wave_walked, &h->packed12};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
@@ -432,6 +434,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     h->have_forward = false;
     h->have_backward = false;
     h->marks_valid = false;
+    h->packed_valid = false;   // (gut_trace_fields sets it again once this call has succeeded)
 
     HIP_TRY(h->tiles_count.ensure(sizeof(uint32_t) * (size_t)n));
     HIP_TRY(h->tiles_offset.ensure(sizeof(uint32_t) * (size_t)n));
@@ -633,12 +636,80 @@ int gut_trace_bwd(gut_handle h, void* stream_, uint32_t frame_number, int32_t nu
                             d_particle_radiance_grad, 0u);
 }
 
+static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                          const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+                          const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                          const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                          const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_particle_density_grad,
+                          float* d_particle_radiance_grad, uint32_t flags, const gut::GradFields& fields);
+
 int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
                      const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
                      const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
                      const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
                      const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_particle_density_grad,
                      float* d_particle_radiance_grad, uint32_t flags) {
+    return trace_bwd_impl(h, stream_, frame_number, num_active_features, num_particles, d_particle_density, d_particle_radiance, width,
+                          height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density, d_ray_radiance_density_grad,
+                          d_ray_hit_distance, d_ray_hit_distance_grad, d_particle_density_grad, d_particle_radiance_grad, flags,
+                          gut::GradFields());
+}
+
+// SplatRaster::trace with the four activated tensors the reference's Tracer hands to _Autograd (tracer.py:317-327) instead of
+// their concatenation: the [N,12] rows are packed into handle scratch by one coalesced kernel (the torch.cat of tracer.py:176-178
+// runs at a quarter of that rate) and stay there for gut_trace_bwd_fields.
+int gut_trace_fields(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                     const float* d_positions, const float* d_density, const float* d_rotation, const float* d_scale,
+                     const float* d_particle_radiance, int32_t width, int32_t height, const float* d_ray_origin,
+                     const float* d_ray_direction, const GutCamera* camera, float* d_ray_radiance_density,
+                     float* d_ray_hit_distance, float* d_ray_hit_count, float* d_particle_visibility) {
+    if (!h) return fail("gut_trace_fields: null handle");
+    if (num_particles && (!d_positions || !d_density || !d_rotation || !d_scale))
+        return fail("gut_trace_fields: null particle buffers with %u particles", num_particles);
+    if (((uintptr_t)d_rotation & 15u) != 0) return fail("gut_trace_fields: the rotation tensor must be 16-byte aligned");
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        DeviceGuard dev_guard;
+        HIP_TRY(dev_guard.set(h->device));
+        h->packed_valid = false;
+        HIP_TRY(h->packed12.ensure(sizeof(float) * 12 * (size_t)num_particles + 64));
+        gut::launch_pack_fields(static_cast<hipStream_t>(stream_), num_particles, d_positions, d_density, d_rotation, d_scale,
+                                h->packed12.as<float>());
+        HIP_TRY(hipGetLastError());
+    }
+    const int rc = gut_trace(h, stream_, frame_number, num_active_features, num_particles, h->packed12.as<float>(), d_particle_radiance,
+                             width, height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density, d_ray_hit_distance,
+                             d_ray_hit_count, d_particle_visibility);
+    if (rc == 0) h->packed_valid = true;
+    return rc;
+}
+
+// SplatRaster::traceBwd for the forward above; the density gradient is written as the four tensors of _Autograd.backward's
+// return value (tracer.py:268-286: no [N,12] tensor, no split, no four .contiguous() copies)
+int gut_trace_bwd_fields(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                         const float* d_particle_radiance, int32_t width, int32_t height, const float* d_ray_origin,
+                         const float* d_ray_direction, const GutCamera* camera, const float* d_ray_radiance_density,
+                         const float* d_ray_radiance_density_grad, const float* d_ray_hit_distance,
+                         const float* d_ray_hit_distance_grad, float* d_positions_grad, float* d_density_grad, float* d_rotation_grad,
+                         float* d_scale_grad, float* d_particle_radiance_grad) {
+    if (!h) return fail("gut_trace_bwd_fields: null handle");
+    if (!h->packed_valid) return fail("gut_trace_bwd_fields: no gut_trace_fields forward on this handle");
+    if (num_particles && (!d_positions_grad || !d_density_grad || !d_rotation_grad || !d_scale_grad || !d_particle_radiance_grad))
+        return fail("gut_trace_bwd_fields: null gradient buffers");
+    if (((uintptr_t)d_rotation_grad & 15u) != 0) return fail("gut_trace_bwd_fields: the rotation gradient must be 16-byte aligned");
+    gut::GradFields f;
+    f.pos = d_positions_grad; f.dns = d_density_grad; f.rot = d_rotation_grad; f.scl = d_scale_grad;
+    return trace_bwd_impl(h, stream_, frame_number, num_active_features, num_particles, h->packed12.as<float>(), d_particle_radiance, width,
+                          height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density, d_ray_radiance_density_grad,
+                          d_ray_hit_distance, d_ray_hit_distance_grad, d_positions_grad /* non-null marker */, d_particle_radiance_grad, 0u, f);
+}
+
+static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                          const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+                          const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                          const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                          const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_particle_density_grad,
+                          float* d_particle_radiance_grad, uint32_t flags, const gut::GradFields& fields) {
     (void)frame_number;
     (void)d_particle_radiance;
     if (!h) return fail("gut_trace_bwd: null handle");
@@ -711,7 +782,7 @@ int gut_trace_bwd_ex(gut_handle h, void* stream_, uint32_t frame_number, int32_t
         else
             gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
                                     h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad,
-                                    (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0);
+                                    (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0, fields);
         h->grad16_zero = true;  // the epilogue zeroed every row K7 could have touched (the rows with tiles)
     }
     mark(11);

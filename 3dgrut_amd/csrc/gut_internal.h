@@ -80,9 +80,18 @@ void launch_pad_keys(hipStream_t s, const uint32_t* count, uint32_t sort_n, uint
 // debug view only: ordered_ids[range.x + tile_ordered[t] .. range.y) := padding id for every tile t
 void launch_mask_unordered(hipStream_t s, uint32_t tiles, const uint32_t* ranges, const uint32_t* tile_ordered, uint32_t* ordered_ids);
 void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, uint32_t* ranges);
+// K8 output as the four tensors of the reference's _Autograd.backward instead of one [N,12] tensor (pos == nullptr: [N,12])
+struct GradFields {
+    float* pos = nullptr;   // [N,3]
+    float* dns = nullptr;   // [N,1]
+    float* rot = nullptr;   // [N,4] (16-byte aligned)
+    float* scl = nullptr;   // [N,3]
+};
 void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
                         const uint32_t* tiles_count, const float* feat, float* grad16 /* rows read are left zero */,
-                        float* density_grad12, float* sph_grad48, bool raw_grads);
+                        float* density_grad12, float* sph_grad48, bool raw_grads, const GradFields& fields = GradFields());
+void launch_pack_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns, const float* rot, const float* scl,
+                        float* density12);
 
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,

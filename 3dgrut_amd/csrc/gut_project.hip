@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
                                                             const uint32_t* __restrict__ tiles_count,
                                                             const float* __restrict__ feat, float4* __restrict__ grad16,
                                                             float4* __restrict__ density_grad12,
-                                                            float4* __restrict__ sph_grad48) {
+                                                            float4* __restrict__ sph_grad48, GradFields fields) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
@@ -767,12 +767,33 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
                 out[3 * k + 2] = Y[k] * m2;
             }
     }
-    density_grad12[3 * (size_t)i + 0] = g0;
-    density_grad12[3 * (size_t)i + 1] = g1;
-    density_grad12[3 * (size_t)i + 2] = g2;
+    if (fields.pos) {
+        // the four gradient tensors the reference's _Autograd.backward hands back (tracer.py:268-286), written directly
+        // instead of one [N,12] tensor that torch then splits and copies four times
+        fields.pos[3 * (size_t)i + 0] = g0.x; fields.pos[3 * (size_t)i + 1] = g0.y; fields.pos[3 * (size_t)i + 2] = g0.z;
+        fields.dns[i] = g0.w;
+        reinterpret_cast<float4*>(fields.rot)[i] = g1;
+        fields.scl[3 * (size_t)i + 0] = g2.x; fields.scl[3 * (size_t)i + 1] = g2.y; fields.scl[3 * (size_t)i + 2] = g2.z;
+    } else {
+        density_grad12[3 * (size_t)i + 0] = g0;
+        density_grad12[3 * (size_t)i + 1] = g1;
+        density_grad12[3 * (size_t)i + 2] = g2;
+    }
 #pragma unroll
     for (int k = 0; k < 12; ++k)
         sph_grad48[12 * (size_t)i + k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+
+// k_pack_fields: (positions [N,3], density [N,1], rotation [N,4], scale [N,3]) -> the [N,12] rows the kernels read
+// ([pos | density | quat wxyz | scale | 0], tracer.py:176-178) — the reference's torch.cat, as one coalesced pass
+__global__ __launch_bounds__(kBlock) void k_pack_fields(uint32_t n, const float* __restrict__ pos, const float* __restrict__ dns,
+                                                       const float4* __restrict__ rot, const float* __restrict__ scl,
+                                                       float4* __restrict__ density12) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    density12[3 * (size_t)i + 0] = make_float4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], dns[i]);
+    density12[3 * (size_t)i + 1] = rot[i];
+    density12[3 * (size_t)i + 2] = make_float4(scl[3 * (size_t)i], scl[3 * (size_t)i + 1], scl[3 * (size_t)i + 2], 0.0f);
 }
 
 // K8c: compact per-Gaussian epilogue for the fused optimiser / compact data-parallel exchange.  Writes the [N,12]
@@ -898,13 +919,20 @@ void launch_tile_ranges(hipStream_t s, uint32_t m, const uint64_t* sorted_keys, 
 
 void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
                         const uint32_t* tiles_count, const float* feat, float* grad16, float* density_grad12,
-                        float* sph_grad48, bool raw_grads) {
+                        float* sph_grad48, bool raw_grads, const GradFields& fields) {
     if (n == 0) return;
     auto kern = raw_grads ? k_project_backward<true> : k_project_backward<false>;
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), tiles_count, feat,
                        reinterpret_cast<float4*>(grad16), reinterpret_cast<float4*>(density_grad12),
-                       reinterpret_cast<float4*>(sph_grad48));
+                       reinterpret_cast<float4*>(sph_grad48), fields);
+}
+
+void launch_pack_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns, const float* rot, const float* scl,
+                        float* density12) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pack_fields, dim3(blocks_for(n)), dim3(kBlock), 0, s, n, pos, dns, reinterpret_cast<const float4*>(rot), scl,
+                       reinterpret_cast<float4*>(density12));
 }
 
 }  // namespace gut

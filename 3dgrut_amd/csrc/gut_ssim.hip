@@ -19,6 +19,16 @@ constexpr int kWin = 11;
 constexpr int kHalo = 5;
 constexpr int kSTile = 16;
 constexpr int kPatch = kSTile + 2 * kHalo;  // 26
+constexpr int kRowStride = 48;              // LDS row stride of a patch, see k_ssim_fwd
+
+// Tile of workgroup b: the eight XCDs take workgroups round-robin (b % 8), so neighbouring tiles — whose 26x26 input patches
+// overlap by 10 pixels — would sit in eight different L2s and every halo would be fetched from memory again (measured: 2.5x the
+// algorithmic bytes).  Each XCD gets one contiguous band of tile rows instead.
+__device__ __forceinline__ void xcd_tile(uint32_t b, uint32_t gx, uint32_t gy, int* tx, int* ty) {
+    const uint32_t n = gx * gy, full = n >> 3;            // tiles per band; the up to seven tiles beyond 8 * full keep t = b
+    const uint32_t t = b < 8u * full ? (b & 7u) * full + (b >> 3) : b;
+    *tx = (int)(t % gx); *ty = (int)(t / gx);
+}
 
 __constant__ float c_gauss[kWin] = {0.001028380123898387f, 0.0075987582094967365f, 0.036000773310661316f,
                                     0.10936068743467331f,  0.21300552785396576f,   0.26601171493530273f,
@@ -46,12 +56,18 @@ __device__ __forceinline__ float load_px(const float* __restrict__ img, const Im
 __global__ __launch_bounds__(256) void k_ssim_fwd(ImgView v, ImgView v2, const float* __restrict__ img1,
                                                  const float* __restrict__ img2, float* __restrict__ partial,
                                                  float* __restrict__ partial_l1, float* __restrict__ dm_dmu1,
-                                                 float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12) {
-    __shared__ float s1[kPatch][kPatch + 1], s2[kPatch][kPatch + 1];
-    __shared__ float h[5][kPatch][kSTile + 1];  // horizontally filtered: mu1, mu2, x^2, y^2, xy
+                                                 float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12,
+                                                 uint32_t gx, uint32_t gy) {
+    // row strides chosen for the two 16-lane rows a 32-lane LDS access group covers: 48 = 16 mod 32 for the patches (row r and
+    // r + 1 fall on disjoint halves of the 32 banks while the 11-tap window slides), 16 for the filtered rows (ditto for the
+    // column pass).  With the earlier 27 / 17 the window passes lost 46 % of their LDS cycles to 2-way conflicts.
+    __shared__ float s1[kPatch][kRowStride], s2[kPatch][kRowStride];
+    __shared__ float h[5][kPatch][kSTile];  // horizontally filtered: mu1, mu2, x^2, y^2, xy
     __shared__ float red[4];
     const int c = blockIdx.z;
-    const int x0 = blockIdx.x * kSTile, y0 = blockIdx.y * kSTile;
+    int tx, ty;
+    xcd_tile(blockIdx.x, gx, gy, &tx, &ty);
+    const int x0 = tx * kSTile, y0 = ty * kSTile;
     const int tid = threadIdx.x;
     for (int i = tid; i < kPatch * kPatch; i += 256) {
         const int py = i / kPatch, pxx = i - py * kPatch;
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(ImgView v, ImgView v2, const f
     for (int mk = 32; mk >= 1; mk >>= 1) val += __shfl_xor(val, mk);
     if ((tid & 63) == 0) red[tid >> 6] = val;
     __syncthreads();
-    const int slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int slot = blockIdx.z * gridDim.x + blockIdx.x;
     if (tid == 0) partial[slot] = red[0] + red[1] + red[2] + red[3];
     if (partial_l1) {  // block-uniform
         __syncthreads();
@@ -158,11 +174,13 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(ImgView v, ImgView v2, const f
                                                  const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
                                                  const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
                                                  const float* __restrict__ upstream, float inv_count, float ssim_weight,
-                                                 float l1_weight, float* __restrict__ grad) {
-    __shared__ float s[3][kPatch][kPatch + 1];
-    __shared__ float h[3][kPatch][kSTile + 1];
+                                                 float l1_weight, float* __restrict__ grad, uint32_t gx, uint32_t gy) {
+    __shared__ float s[3][kPatch][kRowStride];
+    __shared__ float h[3][kPatch][kSTile];
     const int c = blockIdx.z;
-    const int x0 = blockIdx.x * kSTile, y0 = blockIdx.y * kSTile;
+    int tx, ty;
+    xcd_tile(blockIdx.x, gx, gy, &tx, &ty);
+    const int x0 = tx * kSTile, y0 = ty * kSTile;
     const int tid = threadIdx.x;
     const float scale = (upstream ? upstream[0] : ssim_weight) * inv_count;
     for (int i = tid; i < kPatch * kPatch; i += 256) {
@@ -242,12 +260,13 @@ int gut_ssim_forward(void* stream, int32_t channels, int32_t height, int32_t wid
     const size_t plane = (size_t)channels * height * width;
     float* maps = static_cast<float*>(d_workspace);
     float* partial = maps + 3 * plane;
-    const dim3 grid((width + 15) / 16, (height + 15) / 16, channels);
+    const uint32_t gx = (width + 15) / 16, gy = (height + 15) / 16;
+    const dim3 grid(gx * gy, 1, channels);
     const gut::ImgView v = make_view(channels, height, width, stride_c, stride_h, stride_w);
     hipLaunchKernelGGL(gut::k_ssim_fwd, grid, dim3(256), 0, s, v, v, d_img1, d_img2, partial, (float*)nullptr, maps, maps + plane,
-                       maps + 2 * plane);
+                       maps + 2 * plane, gx, gy);
     const double count = (double)channels * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
-    hipLaunchKernelGGL(gut::k_ssim_finish, dim3(1), dim3(256), 0, s, partial, (int)(grid.x * grid.y * grid.z), (float)(1.0 / count),
+    hipLaunchKernelGGL(gut::k_ssim_finish, dim3(1), dim3(256), 0, s, partial, (int)(grid.x * grid.z), (float)(1.0 / count),
                        d_mean_ssim);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -259,11 +278,12 @@ int gut_ssim_backward(void* stream, int32_t channels, int32_t height, int32_t wi
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t plane = (size_t)channels * height * width;
     const float* maps = static_cast<const float*>(d_workspace);
-    const dim3 grid((width + 15) / 16, (height + 15) / 16, channels);
+    const uint32_t gx = (width + 15) / 16, gy = (height + 15) / 16;
+    const dim3 grid(gx * gy, 1, channels);
     const gut::ImgView v = make_view(channels, height, width, stride_c, stride_h, stride_w);
     const double count = (double)channels * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
     hipLaunchKernelGGL(gut::k_ssim_bwd, grid, dim3(256), 0, s, v, v, d_img1, d_img2, maps, maps + plane, maps + 2 * plane, d_upstream,
-                       (float)(1.0 / count), 0.0f, 0.0f, d_grad_img1);
+                       (float)(1.0 / count), 0.0f, 0.0f, d_grad_img1, gx, gy);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -280,21 +300,22 @@ int gut_photometric_loss(void* stream, int32_t height, int32_t width, const floa
     const size_t plane = (size_t)3 * height * width;
     float* maps = static_cast<float*>(d_workspace);
     float* partial = maps + 3 * plane;
-    const dim3 grid((width + 15) / 16, (height + 15) / 16, 3);
-    const int nblocks = (int)(grid.x * grid.y * grid.z);
+    const uint32_t gx = (width + 15) / 16, gy = (height + 15) / 16;
+    const dim3 grid(gx * gy, 1, 3);
+    const int nblocks = (int)(grid.x * grid.z);
     float* partial_l1 = partial + nblocks + 64;
     gut::ImgView v = make_view(3, height, width, 1, 4 * (int64_t)width, 4);   // rgba, interleaved
     v.alpha_offset = 3;
     v.background = background;
     const gut::ImgView g = make_view(3, height, width, 1, 3 * (int64_t)width, 3);  // ground truth, interleaved rgb
     hipLaunchKernelGGL(gut::k_ssim_fwd, grid, dim3(256), 0, s, v, g, d_rgba, d_gt_rgb, partial, partial_l1, maps, maps + plane,
-                       maps + 2 * plane);
+                       maps + 2 * plane, gx, gy);
     const double count = 3.0 * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
     const double numel = 3.0 * height * width;
     hipLaunchKernelGGL(gut::k_photometric_finish, dim3(1), dim3(256), 0, s, partial, partial_l1, nblocks, (float)(1.0 / count),
                        (float)(1.0 / numel), lambda_l1, lambda_ssim, d_loss3);
     hipLaunchKernelGGL(gut::k_ssim_bwd, grid, dim3(256), 0, s, v, g, d_rgba, d_gt_rgb, maps, maps + plane, maps + 2 * plane,
-                       (const float*)nullptr, (float)(1.0 / count), -lambda_ssim, (float)(lambda_l1 / numel), d_rgba_grad);
+                       (const float*)nullptr, (float)(1.0 / count), -lambda_ssim, (float)(lambda_l1 / numel), d_rgba_grad, gx, gy);
     if (background != 0.0f) {
         const int pixels = height * width;
         hipLaunchKernelGGL(gut::k_alpha_grad, dim3((pixels + 255) / 256), dim3(256), 0, s, pixels, background, d_rgba_grad);

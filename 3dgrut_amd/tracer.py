@@ -270,6 +270,66 @@ class SplatRaster:
         _capi.check(rc, "trace_bwd")
         return dens_g, sph_g
 
+    def trace_fields(self, frame_number, num_active_features, mog_pos, mog_dns, mog_rot, mog_scl, particle_radiance, ray_ori, ray_dir,
+                     sensor_params, ts_start, ts_end, pose_start, pose_end):
+        """trace() on the four activated tensors Tracer.render hands to _Autograd (positions [N,3], density [N,1], rotation [N,4],
+        scale [N,3]) instead of their [N,12] concatenation: gut_trace_fields packs the rows inside the library (extension of the
+        reference's surface; a wrapper without it gets the reference's torch.cat + trace())."""
+        ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
+        ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
+        if ray_ori.dim() != 4 or ray_ori.shape[0] != 1:
+            raise RuntimeError("[3dgut] rays must be [1,H,W,3] (the reference renders one view per call)")
+        H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
+        n = int(mog_pos.shape[0])
+        dev = ray_ori.device
+        if n:
+            mog_pos = _check_f32_cuda(mog_pos, "positions", (3,)); mog_dns = _check_f32_cuda(mog_dns, "density", (1,))
+            mog_rot = _check_f32_cuda(mog_rot, "rotation", (4,)); mog_scl = _check_f32_cuda(mog_scl, "scale", (3,))
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+        opts = dict(dtype=torch.float32, device=dev)
+        rgba, dist, hits, vis = torch.empty((H, W, 4), **opts), torch.empty((H, W, 1), **opts), torch.empty((H, W, 1), **opts), torch.empty((n, 1), **opts)
+        cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: t.data_ptr() if n else None
+        with torch.cuda.device(dev):
+            rc = self._lib.gut_trace_fields(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF, int(num_active_features), n,
+                                            ptr(mog_pos), ptr(mog_dns), ptr(mog_rot), ptr(mog_scl), ptr(particle_radiance), W, H,
+                                            ray_ori.data_ptr(), ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(), dist.data_ptr(),
+                                            hits.data_ptr(), ptr(vis))
+        _capi.check(rc, "trace_fields")
+        return rgba, dist, hits, vis
+
+    def trace_bwd_fields(self, frame_number, num_active_features, num_particles, particle_radiance, ray_ori, ray_dir, sensor_params, ts_start,
+                         ts_end, pose_start, pose_end, ray_radiance_density, ray_radiance_density_grd, ray_hit_distance,
+                         ray_hit_distance_grd):
+        """Backward of trace_fields: returns (positions, density, rotation, scale, radiance) gradients as five fresh tensors —
+        what _Autograd.backward hands to autograd, with no [N,12] intermediate, split or copies."""
+        ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
+        ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
+        H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
+        n = int(num_particles)
+        dev = ray_ori.device
+        rgba = _check_f32_cuda(ray_radiance_density, "rayRadianceDensity", (4,))
+        rgba_g = _check_f32_cuda(ray_radiance_density_grd, "rayRadianceDensityGradient", (4,))
+        dist = _check_f32_cuda(ray_hit_distance, "rayHitDistance")
+        dist_g = None if ray_hit_distance_grd is None else _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
+        opts = dict(dtype=torch.float32, device=dev)
+        pos_g, dns_g, rot_g, scl_g = (torch.empty((n, c), **opts) for c in (3, 1, 4, 3))
+        sph_g = torch.empty((n, 48), **opts)
+        if n:
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+        cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: t.data_ptr() if n else None
+        with torch.cuda.device(dev):
+            rc = self._lib.gut_trace_bwd_fields(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF, int(num_active_features), n,
+                                                ptr(particle_radiance), W, H, ray_ori.data_ptr(), ray_dir.data_ptr(), C.byref(cam),
+                                                rgba.data_ptr(), rgba_g.data_ptr(), dist.data_ptr(),
+                                                None if dist_g is None else dist_g.data_ptr(), ptr(pos_g), ptr(dns_g), ptr(rot_g),
+                                                ptr(scl_g), ptr(sph_g))
+        _capi.check(rc, "trace_bwd_fields")
+        return pos_g, dns_g, rot_g, scl_g, sph_g
+
     def optimize_after_bwd(self, num_active_features, camera_position, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps,
                            step, visibility=None, act_out=None, lazy=None):
         """Per-Gaussian backward epilogue + SH-gradient rebuild + Adam in one pass (gut_optimize_after_bwd); follows a
@@ -381,28 +441,50 @@ class Tracer:
         @staticmethod
         def forward(ctx, tracer_wrapper, frame_id, n_active_features, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl,
                     mog_dns, mog_sph, sensor_params, sensor_poses):
+            particle_radiance = mog_sph.contiguous()
+            ctx.frame_id = frame_id
+            ctx.n_active_features = n_active_features
+            ctx.sensor_params = sensor_params
+            ctx.sensor_poses = sensor_poses
+            ctx.tracer_wrapper = tracer_wrapper
+            ctx.set_materialize_grads(False)  # an unused pred_dist arrives as None -> backward variant without dist terms
+            ctx.fields = hasattr(tracer_wrapper, "trace_fields")
+            if ctx.fields:
+                # this library's wrapper packs the [pos | density | quat | scale | 0] rows itself (gut_trace_fields) and returns the
+                # four gradients as four tensors: no torch.cat here (0.43 ms at 6 M Gaussians), no split + four copies in backward
+                rgba, dist, hits, vis = tracer_wrapper.trace_fields(
+                    frame_id, n_active_features, mog_pos, mog_dns, mog_rot, mog_scl, particle_radiance, ray_ori.contiguous(),
+                    ray_dir.contiguous(), sensor_params, sensor_poses.timestamps_us[0], sensor_poses.timestamps_us[1],
+                    sensor_poses.T_world_sensors[0], sensor_poses.T_world_sensors[1])
+                ctx.num_particles = int(mog_pos.shape[0])
+                ctx.save_for_backward(ray_ori, ray_dir, rgba, dist, particle_radiance)
+                ctx.mark_non_differentiable(hits, vis)
+                return rgba, dist, hits, vis
+            # the reference's own form, for any wrapper with the pybind module's surface (trace / trace_bwd on packed rows):
             # [pos(3) | density(1) | quat wxyz(4) | scale(3) | 0] rows, tracer.py:176-178
             particle_density = torch.cat([mog_pos, mog_dns, mog_rot, mog_scl, torch.zeros_like(mog_dns)], dim=1).contiguous()
-            particle_radiance = mog_sph.contiguous()
             ray_time = None  # the reference allocates an int64 [1,H,W,1] tensor that no kernel reads (tracer.py:181-186)
             rgba, dist, hits, vis = tracer_wrapper.trace(
                 frame_id, n_active_features, particle_density, particle_radiance, ray_ori.contiguous(),
                 ray_dir.contiguous(), ray_time, sensor_params, sensor_poses.timestamps_us[0], sensor_poses.timestamps_us[1],
                 sensor_poses.T_world_sensors[0], sensor_poses.T_world_sensors[1])
             ctx.save_for_backward(ray_ori, ray_dir, rgba, dist, particle_density, particle_radiance)
-            ctx.frame_id = frame_id
-            ctx.n_active_features = n_active_features
-            ctx.sensor_params = sensor_params
-            ctx.sensor_poses = sensor_poses
-            ctx.tracer_wrapper = tracer_wrapper
             ctx.mark_non_differentiable(hits, vis)
-            ctx.set_materialize_grads(False)  # an unused pred_dist arrives as None -> backward variant without dist terms
             return rgba, dist, hits, vis
 
         @staticmethod
         def backward(ctx, rgba_grd, dist_grd, hits_grd_unused, vis_grd_unused):
-            ray_ori, ray_dir, rgba, dist, particle_density, particle_radiance = ctx.saved_tensors
             poses = ctx.sensor_poses
+            if ctx.fields:
+                ray_ori, ray_dir, rgba, dist, particle_radiance = ctx.saved_tensors
+                if rgba_grd is None:
+                    rgba_grd = torch.zeros_like(rgba)
+                pos_g, dns_g, rot_g, scl_g, sph_grd = ctx.tracer_wrapper.trace_bwd_fields(
+                    ctx.frame_id, ctx.n_active_features, ctx.num_particles, particle_radiance, ray_ori, ray_dir, ctx.sensor_params,
+                    poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1], rgba,
+                    rgba_grd.contiguous(), dist, None if dist_grd is None else dist_grd.contiguous())
+                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, sph_grd, None, None)
+            ray_ori, ray_dir, rgba, dist, particle_density, particle_radiance = ctx.saved_tensors
             if rgba_grd is None:
                 rgba_grd = torch.zeros_like(rgba)
             dens_grd, sph_grd = ctx.tracer_wrapper.trace_bwd(

@@ -30,7 +30,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout, an array length or an entry point's signature (2: GutStats grew to 80 bytes and
  * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: GutLazyMoments in the gut_optimize_* / gut_sh_adam_step_ex signatures, gut_sync_moments,
- * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev). */
+ * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev, gut_trace_fields / gut_trace_bwd_fields). */
 #define GUT_ABI_VERSION 3
 
 typedef struct gut_context* gut_handle;
@@ -174,6 +174,24 @@ int gut_trace_bwd_ex(gut_handle h, void* stream, uint32_t frame_number, int32_t 
                      const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
                      const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad,
                      float* d_particle_density_grad, float* d_particle_radiance_grad, uint32_t flags);
+
+/* gut_trace / gut_trace_bwd with the particle parameters as the FOUR activated tensors the reference's Tracer.render hands to
+ * _Autograd.apply (positions [N,3], density [N,1], rotation [N,4] wxyz, scale [N,3]; threedgut_tracer/tracer.py:317-327) instead
+ * of the [N,12] concatenation _Autograd.forward builds with torch.cat (:176-178), and with the density gradient returned as the
+ * four tensors _Autograd.backward hands back (:268-286) instead of one [N,12] tensor it splits and copies.  The rows are packed
+ * into handle scratch by one coalesced kernel and kept for the backward; results are those of gut_trace / gut_trace_bwd on the
+ * concatenated rows, bit for bit.  d_rotation / d_rotation_grad must be 16-byte aligned (torch allocations are). */
+int gut_trace_fields(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                     const float* d_positions, const float* d_density, const float* d_rotation, const float* d_scale,
+                     const float* d_particle_radiance, int32_t width, int32_t height, const float* d_ray_origin,
+                     const float* d_ray_direction, const GutCamera* camera, float* d_ray_radiance_density,
+                     float* d_ray_hit_distance, float* d_ray_hit_count, float* d_particle_visibility);
+int gut_trace_bwd_fields(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                         const float* d_particle_radiance, int32_t width, int32_t height, const float* d_ray_origin,
+                         const float* d_ray_direction, const GutCamera* camera, const float* d_ray_radiance_density,
+                         const float* d_ray_radiance_density_grad, const float* d_ray_hit_distance,
+                         const float* d_ray_hit_distance_grad, float* d_positions_grad, float* d_density_grad, float* d_rotation_grad,
+                         float* d_scale_grad, float* d_particle_radiance_grad);
 
 /* SplatRaster::collectTimes — splatRaster.cpp:334-364: mean ms per tag over the timers recorded
  * since the last call; -1 for a tag with no samples. */

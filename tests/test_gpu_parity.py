@@ -513,3 +513,41 @@ def test_forward_queued_before_the_count_is_known_overflow_and_padding():
         assert st["traversed_fwd"] == ref["traversed_fwd"]
     assert counts[1] < counts[0] < counts[2]
     assert overflows == [0, 0, 1, 1], (counts, overflows)
+
+
+def test_field_wise_trace_equals_the_packed_trace():
+    """gut_trace_fields / gut_trace_bwd_fields (what _Autograd calls on this library's wrapper: four activated tensors in, four
+    gradient tensors out, rows packed inside the library) against gut_trace / gut_trace_bwd on the torch.cat-ed [N,12] rows (the
+    reference's own form, still taken for any wrapper with only the pybind surface): images and integer buffers bit-identical,
+    gradients equal up to the float-atomic order of the backward, the same rows exactly zero."""
+    mk, kind, W, H, (eye, tgt), kw = CASES["c1_pinhole_128"]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    model = gut_model(sc, 3)
+    with torch.no_grad():
+        pos, dns, rot, scl = model.positions.detach(), model.get_density(), model.get_rotation(), model.get_scale()
+        sph = model.get_features()
+        d12 = torch.cat([pos, dns, rot, scl, torch.zeros_like(dns)], 1).contiguous()
+    batch = to_batch(view, DEV)
+    sensor, poses = gut.Tracer.create_camera_parameters(batch)
+    ts, ps = poses.timestamps_us, poses.T_world_sensors
+    a, b = gut.Tracer({"render": {}}).tracer_wrapper, gut.Tracer({"render": {}}).tracer_wrapper
+    ro, rd = batch.rays_ori.contiguous(), batch.rays_dir.contiguous()
+    out_a = a.trace(0, 3, d12, sph, ro, rd, None, sensor, ts[0], ts[1], ps[0], ps[1])
+    out_b = b.trace_fields(0, 3, pos, dns, rot, scl, sph, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1])
+    for x, y in zip(out_a, out_b):
+        assert torch.equal(x, y)
+    for key in ("tiles_count", "sorted_ids", "sorted_keys", "tile_ranges"):
+        assert torch.equal(a.debug_buffer(key), b.debug_buffer(key)), key
+    g = torch.randn((H, W, 4), generator=torch.Generator().manual_seed(3)).to(DEV)
+    dg = 0.1 * torch.randn((H, W, 1), generator=torch.Generator().manual_seed(4)).to(DEV)
+    g12, g48 = a.trace_bwd(0, 3, d12, sph, ro, rd, None, sensor, ts[0], ts[1], ps[0], ps[1], out_a[0], g, out_a[1], dg)
+    pg, ng, rg, sg, fg = b.trace_bwd_fields(0, 3, pos.shape[0], sph, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1], out_b[0], g, out_b[1], dg)
+    assert pg.shape == (1000, 3) and ng.shape == (1000, 1) and rg.shape == (1000, 4) and sg.shape == (1000, 3) and fg.shape == (1000, 48)
+    for got, ref in ((pg, g12[:, 0:3]), (ng, g12[:, 3:4]), (rg, g12[:, 4:8]), (sg, g12[:, 8:11]), (fg, g48)):
+        assert torch.equal(got == 0, ref == 0)
+        assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+    # a plain trace() on the handle invalidates the packed rows: the field-wise backward must not run on them
+    b.trace(0, 3, d12, sph, ro, rd, None, sensor, ts[0], ts[1], ps[0], ps[1])
+    with pytest.raises(RuntimeError, match="no gut_trace_fields forward"):
+        b.trace_bwd_fields(0, 3, pos.shape[0], sph, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1], out_b[0], g, out_b[1], dg)
