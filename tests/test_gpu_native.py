@@ -408,12 +408,13 @@ def test_placement_tuning_moves_the_state_without_changing_it():
     before = {k: v.clone() for k, v in state(tuned).items()}
     ptrs = {k: v.data_ptr() for k, v in state(tuned).items()}
     act_before = tuned.activate().clone()
-    times = tuned.tune_placement(trials=4)
-    assert len(times) == 4 and all(t > 0 for t in times) and tuned.placement_trials_ms == times
+    times = tuned.tune_placement(attempts=2)
+    assert 4 <= len(times) <= 7 and all(t > 0 for t in times) and tuned.placement_trials_ms == times   # the start + <= 2 per big tensor
     for k, v in state(tuned).items():
         assert torch.equal(v, before[k]), k
-    moved = any(state(tuned)[k].data_ptr() != ptrs[k] for k in ptrs)
-    assert moved == (times[0] > 1.03 * min(times))
+    moved = [k for k in ptrs if state(tuned)[k].data_ptr() != ptrs[k]]
+    assert set(moved) <= {"features", "m48", "v48"}                     # only the three [N,48] tensors are ever re-placed ...
+    assert bool(moved) == (min(times[1:]) < 0.97 * times[0])            # ... and only for a pass that got > 3 % faster
     assert torch.equal(tuned.activate(), act_before)
     for st in steppers:
         b = to_batch(view, DEV); b.rgb_gt = gt
