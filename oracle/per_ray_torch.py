@@ -238,6 +238,63 @@ def project(cam, tq, W, H, params, dtype=torch.float64):
     return dict(valid=valid, center=center, conic_opacity=torch.cat([conic, op[:, None]], -1), extent=extent, depth=z)
 
 
+def tile_footprints(pr, W, H, tile=16):
+    """Second, vectorised float64 restatement of K1's tile rules on top of project()'s output (independent code path from
+    gut_oracle.c): the tile bounding box of gutProjector.cuh:32-43 (`pos - 0.5 +- extent`, floor / ceil, clamped to the grid) and
+    the per-tile culling of :49-78 (power of the Gaussian at the rectangle point the reference picks, kept iff below
+    ln(255 * opacity) = ln(opacity / min_alpha)), evaluated densely for every (Gaussian, tile) pair.
+    Returns dict(in_box [N,T] bool, power [N,T], threshold [N], kept [N,T] bool, exact_min_power [N,T]) with T = tiles of the grid,
+    row-major.  exact_min_power is the TRUE minimum of the same quadratic form over the tile rectangle (a convex function over a
+    rectangle: zero if the mean is inside, else the smallest of the four clamped 1-D edge minima) — the reference evaluates the
+    form at a feasible point of the rectangle, so power >= exact_min_power: a kept tile provably intersects the footprint."""
+    c, e, co = pr["center"], pr["extent"], pr["conic_opacity"]
+    dt = c.dtype
+    gx, gy = (W + tile - 1) // tile, (H + tile - 1) // tile
+    x0 = torch.floor((c[:, 0] - 0.5 - e[:, 0]) / tile).clamp(min=0, max=gx)
+    y0 = torch.floor((c[:, 1] - 0.5 - e[:, 1]) / tile).clamp(min=0, max=gy)
+    x1 = torch.ceil((c[:, 0] - 0.5 + e[:, 0]) / tile).clamp(min=0, max=gx)
+    y1 = torch.ceil((c[:, 1] - 0.5 + e[:, 1]) / tile).clamp(min=0, max=gy)
+    tx = torch.arange(gx, dtype=dt).repeat(gy)[None]               # [1,T] tile column
+    ty = torch.arange(gy, dtype=dt).repeat_interleave(gx)[None]    # [1,T] tile row
+    in_box = pr["valid"][:, None] & (tx >= x0[:, None]) & (tx < x1[:, None]) & (ty >= y0[:, None]) & (ty < y1[:, None])
+    a, b, cc, op = (co[:, k][:, None] for k in range(4))
+    mx, my = c[:, 0][:, None], c[:, 1][:, None]
+    tminx, tminy = tile * tx, tile * ty
+    tmaxx, tmaxy = tminx + tile, tminy + tile
+    # --- the reference's point (gutProjector.cuh:57-74)
+    offx, offy = tminx - mx, tminy - my
+    lax, lay = (offx > 0).to(dt), (offy > 0).to(dt)
+    nrx, nry = lax + (mx > tmaxx).to(dt), lay + (my > tmaxy).to(dt)
+    px = torch.where(lax > 0, tminx, tmaxx)
+    py = torch.where(lay > 0, tminy, tmaxy)
+    dxx = torch.where(offx >= 0, torch.full_like(offx, float(tile)), torch.full_like(offx, -float(tile)))   # copysign(tile, offset)
+    dyy = torch.where(offy >= 0, torch.full_like(offy, float(tile)), torch.full_like(offy, -float(tile)))
+    fx_, fy_ = mx - px, my - py
+    sx = nry * ((dxx * a * fx_ + dxx * b * fy_) / (tile * tile * a)).clamp(0, 1)
+    sy = nrx * ((dyy * b * fx_ + dyy * cc * fy_) / (tile * tile * cc)).clamp(0, 1)
+    qx, qy = mx - (px + sx * dxx), my - (py + sy * dyy)
+    power = 0.5 * (a * qx * qx + cc * qy * qy) + b * qx * qy
+    power = torch.where((nrx + nry) > 0, power, torch.zeros_like(power))
+    thr = torch.log(op[:, 0] / ALPHA_MIN)
+    kept = in_box & (power < thr[:, None])
+    # --- exact minimum of q(d) = 0.5 (a dx^2 + c dy^2) + b dx dy over the rectangle, d = mean - point
+    def q(dx_, dy_):
+        return 0.5 * (a * dx_ * dx_ + cc * dy_ * dy_) + b * dx_ * dy_
+    inside = (mx >= tminx) & (mx <= tmaxx) & (my >= tminy) & (my <= tmaxy)
+    cands = []
+    for xe in (tminx, tmaxx):        # vertical edges: x fixed, minimise over y in [tminy, tmaxy]: dq/ddy = c dy + b dx = 0
+        dx_ = mx - xe
+        ystar = torch.minimum(torch.maximum(my + b * dx_ / cc, tminy), tmaxy)
+        cands.append(q(dx_, my - ystar))
+    for ye in (tminy, tmaxy):        # horizontal edges
+        dy_ = my - ye
+        xstar = torch.minimum(torch.maximum(mx + b * dy_ / a, tminx), tmaxx)
+        cands.append(q(mx - xstar, dy_))
+    exact = torch.stack(cands, 0).min(0).values
+    exact = torch.where(inside, torch.zeros_like(exact), exact)
+    return dict(in_box=in_box, power=power, threshold=thr, kept=kept, exact_min_power=exact, grid=(gx, gy))
+
+
 def render_per_ray(cam, tq, W, H, params, ray_ori, ray_dir, sh_degree=3, dtype=torch.float32, pix_chunk=4096,
                    gauss_chunk=512, pixel_subset=None):
     """Brute-force per-ray composite (no tiles): cull by the UT rule, sort by camera z, composite."""

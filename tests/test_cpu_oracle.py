@@ -276,3 +276,45 @@ def test_flip_budget_covers_what_a_threshold_perturbation_moves():
             assert not err[budget[:, j] == 0].any()
             moved_rows += int((err > 1e-9 * nr + 1e-12 * scale).sum())
     assert moved_rows > 0
+
+
+@pytest.mark.parametrize("kind,W,H", [("pinhole", 128, 96), ("fisheye", 144, 96), ("pinhole", 100, 70)])
+def test_tile_rules_against_an_independent_float64_restatement(kind, W, H):
+    """K1's tile bounding box and per-tile culling (gutProjector.cuh:32-78) — the rules every integer buffer rests on, and which
+    the GPU shares with the C oracle bit for bit — against a second, vectorised float64 restatement (per_ray_torch.tile_footprints)
+    evaluated densely for every (Gaussian, tile) pair:
+      * the set of tiles each Gaussian keeps is identical, except pairs whose power sits within 1e-4 (relative) of the threshold
+        or whose box edge sits within 1e-3 px of a tile boundary (fp32 vs fp64);
+      * soundness: the reference evaluates the footprint's quadratic form at ONE point of the tile, so its value bounds the true
+        minimum over the tile from above — every kept tile provably intersects the footprint;
+      * how much the one-point rule gives away (tiles culled although the true minimum is below the threshold) is reported."""
+    sc = scenes.scene_c1(1500, seed=29)
+    sc["scale"] *= np.random.default_rng(1).uniform(0.3, 3.0, size=(1500, 1)).astype(np.float32)   # sub-tile splats up to multi-tile ones
+    eye = (0.3, 0.2, -3.5) if kind == "pinhole" else (0.2, 0.1, -1.6)
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, (0, 0, 0)), fx=0.9 * W if kind == "pinhole" else None)
+    f = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in sc.items()}
+    pr = prt.project(view["oracle_cam"], view["tq"], W, H, params)
+    fp = prt.tile_footprints(pr, W, H)
+    gx, gy = fp["grid"]
+    T = gx * gy
+    # the oracle's kept pairs, from its unsorted key list (tile index in the high word), as a dense [N,T] matrix
+    kept_c = np.zeros((1500, T), bool)
+    kept_c[f["unsorted_ids"].astype(np.int64), (f["unsorted_keys"] >> np.uint64(32)).astype(np.int64)] = True
+    assert kept_c.sum() == f["M"] and np.array_equal(kept_c.sum(1), f["tiles_count"])
+    kept_t = fp["kept"].numpy()
+    power, thr = fp["power"].numpy(), fp["threshold"].numpy()[:, None]
+    c, e = pr["center"].numpy(), pr["extent"].numpy()
+    edge = np.minimum.reduce([np.abs(((c[:, 0] - 0.5 - e[:, 0]) / 16 + 0.5) % 1 - 0.5), np.abs(((c[:, 0] - 0.5 + e[:, 0]) / 16 + 0.5) % 1 - 0.5),
+                              np.abs(((c[:, 1] - 0.5 - e[:, 1]) / 16 + 0.5) % 1 - 0.5), np.abs(((c[:, 1] - 0.5 + e[:, 1]) / 16 + 0.5) % 1 - 0.5)])
+    touchy = (np.abs(power - thr) <= 1e-4 * np.maximum(np.abs(thr), 1.0)) | (edge[:, None] < 1e-3 / 16)
+    differ = kept_c != kept_t
+    assert not (differ & ~touchy).any(), f"{int((differ & ~touchy).sum())} (Gaussian, tile) pairs differ away from any threshold"
+    assert differ.sum() <= 5 and kept_t.sum() > 2000 and (fp["in_box"].numpy() & ~kept_t).sum() > 200   # culling is exercised both ways
+    # soundness of the one-point rule
+    exact = fp["exact_min_power"].numpy()
+    assert (exact <= power + 1e-9 * np.maximum(np.abs(power), 1.0)).all()
+    assert (exact[kept_t] < thr.repeat(T, 1)[kept_t] * (1 + 1e-9) + 1e-12).all()
+    lost = fp["in_box"].numpy() & ~kept_t & (exact < thr)
+    print(f"[tile rule {kind} {W}x{H}] kept {int(kept_t.sum())} of {int(fp['in_box'].numpy().sum())} boxed pairs; "
+          f"{int(lost.sum())} culled although the footprint reaches the tile (the reference's one-point rule)")
