@@ -292,7 +292,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
         model = native_mod.NativeGaussianModel(scene, device=dev, sh_degree=sh_degree, spatial_order=not args.scene_order)
         stepper = native_mod.NativeTrainStep(model, tracer, scene_extent=extent, world_size=world, selective=args.selective_adam,
                                              rank=rank, fused_sh_adam=not args.dense_exchange,
-                                             overlap_optimizer=False if args.no_overlap_optimizer else None,
+                                             overlap_optimizer=False if args.no_overlap_optimizer else (True if getattr(args, "force_overlap_optimizer", False) else None),
                                              dp_exchange=args.dp_exchange, dp_side_stream=not args.no_dp_side_stream,
                                              lazy_moments=not getattr(args, "no_lazy_moments", False))
         if not getattr(args, "fresh_optimizer_state", False):
@@ -344,9 +344,9 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
 
     for s in range(warmup):
         stepper.step(batch_for(s))
-    # the trainer's overlap probe times steps 1..4 in alternating forms and decides at step 5: never inside the timed region
+    # the trainer's overlap probe times steps 2..9 in alternating forms and decides at step 10: never inside the timed region
     extra_warmup = 0
-    while getattr(stepper, "_overlap_probe", None) is not None and not stepper._overlap_probe["done"] and extra_warmup < 8:
+    while getattr(stepper, "_overlap_probe", None) is not None and not stepper._overlap_probe["done"] and extra_warmup < 12:
         stepper.step(batch_for(warmup + extra_warmup))
         extra_warmup += 1
     warmup += extra_warmup
@@ -462,6 +462,8 @@ def main():
     ap.add_argument("--no-lazy-moments", action="store_true",
                     help="write both Adam moments of every row every step (default: waves that cannot receive a gradient read their moments, "
                          "bring them up to date in registers and do not write them back; gut_hip.h: GutLazyMoments)")
+    ap.add_argument("--force-overlap-optimizer", action="store_true",
+                    help="always use the side-stream optimiser pass (default: the trainer times both forms in steps 1-4 and keeps the faster)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
                     help="one optimiser kernel after the backward instead of the side-stream pass for the waves that cannot receive a gradient")
     args = ap.parse_args()

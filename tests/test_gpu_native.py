@@ -622,8 +622,8 @@ def test_selective_adam_inside_the_fused_optimiser_kernel():
 
 
 def test_overlap_probe_keeps_the_faster_optimiser_form(monkeypatch):
-    """With the overlap on by default NativeTrainStep times steps 1..4 alternately with and without it and keeps the faster
-    form; forced settings are never probed.  (Made applicable to a small scene by lowering the size gate.)"""
+    """With the overlap on by default NativeTrainStep times steps 2..9 alternately with and without it and keeps the form whose
+    best sample is faster; forced settings are never probed.  (Made applicable to a small scene by lowering the size gate.)"""
     sc = scenes.scene_c1(4000, 9)
     W, H = 96, 64
     view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, 0.0, -3.5), (0, 0, 0)), fx=90.0)
@@ -635,11 +635,11 @@ def test_overlap_probe_keeps_the_faster_optimiser_form(monkeypatch):
     monkeypatch.setattr(native.NativeTrainStep, "OVERLAP_MIN_GAUSSIANS", 1000)
     st = native.NativeTrainStep(model2, gut.Tracer({"render": {}}))
     assert st.overlap_optimizer and st._overlap_probe is not None
-    for _ in range(10):
+    for _ in range(14):
         b = to_batch(view, DEV); b.T_to_world = b.T_to_world.cpu(); b.rgb_gt = gt
         loss, _ = st.step(b)
         torch.cuda.synchronize()
     p = st._overlap_probe
-    assert p["done"] and len(p["on"]) == 2 and len(p["off"]) == 2 and p["ms_on"] > 0 and p["ms_off"] > 0
+    assert p["done"] and len(p["on"]) == 4 and len(p["off"]) == 4 and p["ms_on"] > 0 and p["ms_off"] > 0
     assert st.overlap_optimizer == (p["ms_on"] <= p["ms_off"])
     assert np.isfinite(float(loss))
