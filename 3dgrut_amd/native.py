@@ -214,6 +214,14 @@ class NativeTrainStep:
         self.phase_timing = False   # record HIP events around the phases of step() (bench / profiling)
         self._phase_events = []
 
+    @property
+    def probe_pending(self):
+        """True while the default-on optimiser overlap is still being timed against the one-pass form (steps PROBE_FIRST ..
+        PROBE_LAST of single-view steps with the fused epilogue; data-parallel and hooked steps never probe)."""
+        p = self._overlap_probe
+        one_pass = self.fused and self.world_size <= 1 and not self.force_exchange and self.post_backward_hook is None and self.fuse_epilogue
+        return p is not None and not p["done"] and one_pass and not self.selective
+
     def resize_workspace(self):
         """(Re)allocate the per-step buffers for the current number of Gaussians (called after densification)."""
         n = self.model.num_gaussians

@@ -346,7 +346,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
         stepper.step(batch_for(s))
     # the trainer's overlap probe times steps 2..9 in alternating forms and decides at step 10: never inside the timed region
     extra_warmup = 0
-    while getattr(stepper, "_overlap_probe", None) is not None and not stepper._overlap_probe["done"] and extra_warmup < 12:
+    while getattr(stepper, "probe_pending", False) and extra_warmup < 12:
         stepper.step(batch_for(warmup + extra_warmup))
         extra_warmup += 1
     warmup += extra_warmup
