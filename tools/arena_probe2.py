@@ -19,7 +19,7 @@ keep = []
 def timed(reps=4):
     def call():
         rc = lib.gut_adam_unwalked_waves_ex(C.c_void_p(st.cuda_stream), N, flags.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
-                                            t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(), z12, z48, 1.0, 1.0, 1e-15, 0, t[6].data_ptr(), 0)
+                                            t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(), z12, z48, 1.0, 1.0, 1e-15, 0, t[6].data_ptr(), None)
         assert rc == 0
     call(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
