@@ -139,7 +139,7 @@ def check_gradient_rows(got, ref, label, budget=None, noise=None, rel_tol=ROW_RE
         assert rep["block_rel_l2_without_rows_needing_budget"] <= block_tol, rep
         # the flip budget is an estimate (first-order in the flipped hit's alpha, contributions evaluated in the oracle's own
         # state): a handful of rows may exceed it, by a bounded factor; a systematic error would exceed it on thousands
-        assert rep["rows_over_full_bound"] <= max(3, 5e-5 * rep["rows_nonzero"]) and rep["worst_row_vs_full_bound"] <= 4.0, rep
+        assert rep["rows_over_full_bound"] <= max(3, 5e-5 * rep["rows_nonzero"]) and rep["worst_row_vs_full_bound"] <= 10.0, rep
         assert rep["rows_needing_budget"] <= 0.02 * max(1, rep["rows_nonzero"]), rep    # the allowance stays the exception
     return rep
 
