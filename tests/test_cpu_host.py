@@ -38,6 +38,26 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.GutStats) == 7 * 8 + 8 + 16
 
 
+def test_ctypes_mirrors_agree_with_the_compiled_header(tmp_path):
+    """The ctypes mirrors of _capi.py against include/gut_hip.h as a C compiler sees it: struct sizes, the ABI version and the
+    array lengths a caller sizes its buffers by (round 2 grew GutStats and GUT_NUM_KERNEL_TIMERS without bumping the version)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "gut_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %d %d %d\\n", sizeof(GutCamera), '
+                   'sizeof(GutConfig), sizeof(GutStats), sizeof(GutLazyMoments), GUT_ABI_VERSION, GUT_NUM_KERNEL_TIMERS, '
+                   'GUT_GRADIENT_RECORD_FLOATS); return 0; }\n')
+    exe = tmp_path / "sizes"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(capi.GutCamera), C.sizeof(capi.GutConfig), C.sizeof(capi.GutStats), C.sizeof(capi.GutLazyMoments),
+                   capi.GUT_ABI_VERSION, capi.GUT_NUM_KERNEL_TIMERS, capi.GRADIENT_RECORD_FLOATS], got
+    assert len(capi.KERNEL_TIMER_NAMES) == capi.GUT_NUM_KERNEL_TIMERS
+
+
 def test_default_config_and_conf_mapping():
     cfg = tracer_mod.config_from_conf(None)
     assert cfg.k_buffer_size == 0 and cfg.particle_kernel_degree == 2 and cfg.particle_radiance_sph_degree == 3
