@@ -273,7 +273,7 @@ class NativeTrainStep:
         """Bring every stored Adam moment up to the last step applied (gut_sync_moments).  Call before reading m12 / v12 / m48 /
         v48, and before anything that moves rows between 64-row waves (reorder and the strategy's row surgery do)."""
         lz = self._lazy()
-        if lz is None or self.model.num_gaussians == 0:
+        if lz is None or self.model.num_gaussians == 0 or not self.model.raw.is_cuda:
             return
         st = torch.cuda.current_stream(self.model.raw.device).cuda_stream
         with torch.cuda.device(self.model.raw.device):
@@ -480,7 +480,8 @@ class NativeTrainStep:
                 t_on = min((a.elapsed_time(b) for a, b in probe["on"]), default=float("inf"))
                 t_off = min((a.elapsed_time(b) for a, b in probe["off"]), default=float("inf"))
                 probe.update(done=True, ms_on=t_on, ms_off=t_off)
-                self.overlap_optimizer = use_overlap = bool(probe["on"]) and bool(probe["off"]) and t_on <= t_off
+                if probe["on"] and probe["off"]:   # (a trainer whose step counter starts beyond the probing steps keeps the default)
+                    self.overlap_optimizer = use_overlap = t_on <= t_off
         early = one_pass and use_overlap and not self.selective
         self._probe_evs = probe_evs
         rgba, dist_, hits, vis = self.forward(batch)
