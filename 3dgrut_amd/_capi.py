@@ -73,7 +73,7 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
            "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_compact_gradient_rows", "gut_scatter_gradient_records",
            "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation",
-           "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev", "gut_adam_unwalked_waves_ex", "gut_sync_moments", "gut_trace_fields", "gut_trace_bwd_fields")
+           "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev", "gut_adam_unwalked_waves_ex", "gut_sync_moments", "gut_trace_fields", "gut_trace_bwd_fields", "gut_selective_adam")
 
 _lib = None
 
@@ -129,6 +129,7 @@ def load():
                                                        u32, vp, lazy_p]
     lib.gut_sync_moments.argtypes = [vp, u32, vp, vp, vp, vp, lazy_p, u32]
     lib.gut_optimize_finish_without_gradient.argtypes = [vp, vp]
+    lib.gut_selective_adam.argtypes = [vp, C.c_uint64, u32, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.gut_set_option.argtypes = [vp, i32, i32]
     lib.gut_mcmc_relocation.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.gut_sh_adam_step.argtypes = [vp, u32, i32, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, fptr, fptr,

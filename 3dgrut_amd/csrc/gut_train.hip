@@ -62,6 +62,23 @@ __global__ __launch_bounds__(kBlock) void k_adam_step(AdamParams ap, uint64_t n_
     v[idx] = vv;
 }
 
+// k_selective_adam: the reference's SelectiveAdam update for ANY row width (its parameters are [N,3], [N,1], [N,4], [N,45] tensors;
+// k_adam_step above wants whole float4 groups) — optimizers.cu:47-79: one element per lane, rows with visibility == 0 untouched
+// (no moment decay either), no bias correction.  The mask is one BYTE per row (a torch.bool tensor).
+__global__ __launch_bounds__(kBlock) void k_selective_adam(uint64_t n_elements, uint32_t cols, float* __restrict__ p,
+                                                          const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          const uint8_t* __restrict__ visibility, float lr, float b1, float b2, float eps) {
+    const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= n_elements) return;
+    if (!visibility[idx / cols]) return;
+    const float gg = g[idx];
+    const float mm = b1 * m[idx] + (1.0f - b1) * gg;
+    const float vv = b2 * v[idx] + (1.0f - b2) * gg * gg;
+    p[idx] += -lr * mm / (sqrtf(vv) + eps);
+    m[idx] = mm;
+    v[idx] = vv;
+}
+
 // k_mcmc_relocation: new opacity / scale of Gaussians sampled `ratio` times by the MCMC relocation
 // (reference: threedgrut/strategy/src/gaussian_mcmc.cu:33-73; binoms is the [n_max,n_max] Pascal table)
 __global__ __launch_bounds__(kBlock) void k_mcmc_relocation(int n, const float* __restrict__ opacities,
@@ -762,6 +779,18 @@ int gut_adam_step(void* stream, uint64_t rows, uint32_t cols, float* d_param, co
     hipLaunchKernelGGL(gut::k_adam_step, dim3((uint32_t)blocks), dim3(gut::kBlock), 0, static_cast<hipStream_t>(stream), ap, n_vec4,
                        reinterpret_cast<float4*>(d_param), reinterpret_cast<const float4*>(d_grad),
                        reinterpret_cast<float4*>(d_exp_avg), reinterpret_cast<float4*>(d_exp_avg_sq), d_visibility);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int gut_selective_adam(void* stream, uint64_t rows, uint32_t cols, float* d_param, const float* d_grad, float* d_exp_avg,
+                       float* d_exp_avg_sq, const uint8_t* d_visibility, float lr, float beta1, float beta2, float eps) {
+    if (rows == 0 || cols == 0) return 0;
+    if (!d_param || !d_grad || !d_exp_avg || !d_exp_avg_sq || !d_visibility) return 1;
+    const uint64_t n = rows * cols;
+    const uint64_t blocks = (n + gut::kBlock - 1) / gut::kBlock;
+    if (blocks > 0x7fffffffull) return 4;
+    hipLaunchKernelGGL(gut::k_selective_adam, dim3((uint32_t)blocks), dim3(gut::kBlock), 0, static_cast<hipStream_t>(stream), n, cols,
+                       d_param, d_grad, d_exp_avg, d_exp_avg_sq, d_visibility, lr, beta1, beta2, eps);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

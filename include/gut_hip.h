@@ -292,6 +292,13 @@ typedef struct GutLazyMoments {
 int gut_sync_moments(void* stream, uint32_t num_particles, float* d_raw_m, float* d_raw_v, float* d_sh_m, float* d_sh_v,
                      const GutLazyMoments* lazy, uint32_t step /* the last optimiser step applied */);
 
+/* lib_optimizers_cc.selective_adam_update (threedgrut/optimizers/optimizers.cu:47-117, bound in optimizers/__init__.py:113-123):
+ * the SelectiveAdam update of one [rows, cols] fp32 parameter of ANY width, rows whose visibility byte is 0 untouched, no bias
+ * correction.  d_visibility: one byte per row (a torch.bool tensor).  3dgrut_amd/optimizers.py wraps it in the reference's
+ * `SelectiveAdam(torch.optim.Adam)` class. */
+int gut_selective_adam(void* stream, uint64_t rows, uint32_t cols, float* d_param, const float* d_grad, float* d_exp_avg,
+                       float* d_exp_avg_sq, const uint8_t* d_visibility, float lr, float beta1, float beta2, float eps);
+
 /* Fused "SH gradient + Adam" step of the native trainer.  For every Gaussian: Adam on the raw [N,12] row with
  * d_raw_grad12 (already summed over views), then the [N,48] SH row with the gradient
  *     sum_v Y_k(normalize(pos - camera_position[v])) * mrgb[v][i][c]   (k < (sh_degree+1)^2, else 0)
