@@ -77,8 +77,9 @@ def test_selective_adam_class_follows_the_reference_kernel(cols):
         opt.step(vis.float().reshape(-1, 1).to(DEV))        # mog_visibility arrives as a float [N,1] tensor
         opt.zero_grad()
         gd = grad.double()
-        m_new = 0.9 * ref_m + 0.1 * gd
-        v_new = 0.999 * ref_v + 0.001 * gd * gd
+        b1, b2 = np.float32(0.9), np.float32(0.999)     # the kernel holds the betas in fp32: 1 - b2 = 0.0010000467
+        m_new = float(b1) * ref_m + float(np.float32(1) - b1) * gd
+        v_new = float(b2) * ref_v + float(np.float32(1) - b2) * gd * gd
         upd = -0.01 * m_new / (v_new.sqrt() + 1e-15)
         sel = vis[:, None].expand_as(ref_p)
         ref_p = torch.where(sel, ref_p + upd, ref_p); ref_m = torch.where(sel, m_new, ref_m); ref_v = torch.where(sel, v_new, ref_v)
