@@ -546,10 +546,11 @@ def main():
                                             "frac": (traffic or abytes) / (pk(dom)["duration_ms_SQ_A"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                             "source": prof.get("_source")}
         if dom == "optimizer_early_2":
-            roofline["note"] = ("side-stream optimiser pass, second launch: a persistent kernel of one workgroup per CU that streams the "
-                                "Adam state of the Gaussians the forward walked nothing of UNDER the VALU-bound backward compositor and "
-                                "then beside the pass over the walked waves; it shares the chip by design, alone it runs at the box's "
-                                "device-copy rate (profiles/: optimizer_early_2, PMC pass)")
+            roofline["note"] = ("side-stream optimiser pass, second launch: a persistent kernel of two workgroups per CU that streams the "
+                                "Adam state of the Gaussians the forward walked nothing of (lazy moment decay: p, m, v read, p and the next "
+                                "activation row written) UNDER the VALU-bound backward compositor and then beside the pass over the walked "
+                                "waves; it shares the chip by design and is no longer on the step's critical path; alone it runs at the "
+                                "box's device-copy rate (profiles/: optimizer_early_2, PMC pass)")
         if split:
             # context for the split optimiser: what the whole Adam step must move vs what of it is left on the critical path
             roofline["optimizer_split"] = {
