@@ -572,6 +572,52 @@ def test_lazy_moment_decay_equals_writing_the_moments_every_step():
     assert all(torch.equal(getattr(lazy, k), v) for k, v in snap.items())
 
 
+def test_lazy_moments_over_more_steps_than_the_decay_tables_hold():
+    """1100 train steps on rotating views (the beta^k tables hold 1024 entries; the trainer brings every wave up to date every 512
+    steps): no wave's missed steps ever run off the tables, everything stays finite, and the rows no view ever touched agree with
+    the trainer that writes its moments every step — second moments to 1e-5 (beta2^1100 = 0.33 in three table look-ups against 1100
+    roundings), parameters to 1e-6."""
+    sc = scenes.scene_c1(20000, 31)
+    W, H = 96, 72
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(8)).to(DEV)
+    dirs = [(1, 0, 0), (-1, 0.2, 0), (0, 1, 0.1), (0.1, -1, 0)]
+    views = [make_view("pinhole", W, H, cams.look_at_c2w((0.05 * k, 0.0, 0.02 * k), d), fx=90.0) for k, d in enumerate(dirs)]
+    batches = []
+    for v in views:
+        b = to_batch(v, DEV); b.T_to_world = b.T_to_world.cpu(); b.rgb_gt = gt
+        batches.append(b)
+    steppers = {}
+    for lazy in (False, True):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+        st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, overlap_optimizer=True, lazy_moments=lazy)
+        g = torch.Generator(device=DEV).manual_seed(7)
+        for m_, v_ in ((st.m12, st.v12), (st.m48, st.v48)):
+            m_.normal_(0.0, 1e-4, generator=g)
+            v_.fill_(1e-6)
+        steppers[lazy] = st
+    eager, lazy = steppers[False], steppers[True]
+    touched = torch.zeros(20000, dtype=torch.bool, device=DEV)
+    worst_missed = 0
+    for k in range(1100):
+        for st in (eager, lazy):
+            st.step(batches[k % 4])
+        if k < 4:
+            cnt = lazy.raster.debug_buffer("tiles_count")
+            touched |= ~exact_wave_mask(cnt, _rows_in_unwalked_waves(lazy.raster, 20000))
+        if k % 100 == 99 or k in (510, 511, 512, 1023, 1024):
+            worst_missed = max(worst_missed, int(lazy.step_id - lazy.wave_step.min()))
+    assert lazy.step_id == 1100 and worst_missed <= 512 < lazy.LAZY_TABLE        # synced at 512 and 1024
+    lazy.sync_moments()
+    never = ~touched
+    assert int(never.sum()) > 2000
+    for st in (eager, lazy):
+        assert all(bool(torch.isfinite(t).all()) for t in (st.model.raw, st.model.features, st.m12, st.v12, st.m48, st.v48, st.act))
+    for name in ("v12", "v48"):
+        assert torch.allclose(getattr(eager, name)[never], getattr(lazy, name)[never], rtol=1e-5, atol=0.0), name
+    assert torch.allclose(eager.model.raw[never], lazy.model.raw[never], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(eager.model.features[never], lazy.model.features[never], rtol=1e-6, atol=1e-7)
+
+
 def test_spatial_storage_order_is_transparent():
     """NativeGaussianModel(spatial_order=True) only permutes the rows: same image, and after two train steps the parameters
     are those of the scene-order model, row for row through `permutation` (up to the float-atomic noise of the backward);
