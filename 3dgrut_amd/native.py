@@ -161,8 +161,9 @@ class NativeTrainStep:
         self.lazy_moments = bool(lazy_moments) and self.fused and not selective
         self.LAZY_TABLE = 1024
         k = np.arange(self.LAZY_TABLE, dtype=np.float64)
-        self._pow1 = torch.as_tensor((float(betas[0]) ** k).astype(np.float32), device=dev)
-        self._pow2 = torch.as_tensor((float(betas[1]) ** k).astype(np.float32), device=dev)
+        # powers of the fp32 betas the kernels multiply by (0.999f is 0.999000013: over 1000 steps the double's powers would drift 1.3e-5)
+        self._pow1 = torch.as_tensor((float(np.float32(betas[0])) ** k).astype(np.float32), device=dev)
+        self._pow2 = torch.as_tensor((float(np.float32(betas[1])) ** k).astype(np.float32), device=dev)
         self.wave_step = None
         self.step_id = 0
         self.fused_loss = bool(fused_loss)
