@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from .dp import allreduce_mean_
 from .losses import photometric_loss
+from .optimizers import SelectiveAdam
 
 
 def _gauss_window(size=11, sigma=1.5, device="cpu", dtype=torch.float32):
@@ -57,14 +58,24 @@ def photometric_loss_torch(pred_rgb, gt_rgb, lambda_l1=0.8, lambda_ssim=0.2, win
 
 
 class TrainStep:
-    def __init__(self, model, tracer, scene_extent=1.0, world_size=1, fused_adam=True, schedule=None):
+    def __init__(self, model, tracer, scene_extent=1.0, world_size=1, fused_adam=True, schedule=None, optimizer_type="adam"):
+        """optimizer_type: configs/base_gs.yaml:82 `optimizer.type` — "adam" (torch.optim.Adam) or "selective_adam" (model.py:512-513:
+        the reference's SelectiveAdam plugin, here optimizers.SelectiveAdam over `gut_selective_adam`; the step then passes the view's
+        visibility, trainer.py:747-749)."""
         self.model = model
         self.tracer = tracer
         self.world_size = world_size
-        kw = dict(eps=1e-15)
-        if fused_adam and next(model.parameters()).is_cuda:
-            kw["fused"] = True
-        self.optimizer = torch.optim.Adam(model.param_groups(scene_extent), **kw)
+        if optimizer_type == "adam":
+            kw = dict(eps=1e-15)
+            if fused_adam and next(model.parameters()).is_cuda:
+                kw["fused"] = True
+            self.optimizer = torch.optim.Adam(model.param_groups(scene_extent), **kw)
+        elif optimizer_type == "selective_adam":
+            if world_size > 1:
+                raise ValueError("selective_adam masks by ONE view's visibility: it has no data-parallel form (the reference trains single-GPU)")
+            self.optimizer = SelectiveAdam(model.param_groups(scene_extent), eps=1e-15)
+        else:
+            raise ValueError(f"Unknown optimizer type: {optimizer_type}")
         self.window = _gauss_window(device=next(model.parameters()).device)
         self.step_id = 0
         self.schedule = schedule   # schedule.TrainSchedule or None (constant rates, fixed SH degree)
@@ -86,7 +97,11 @@ class TrainStep:
         loss.backward()
         if self.world_size > 1:
             self.allreduce_gradients()
-        self.optimizer.step()
+        if isinstance(self.optimizer, SelectiveAdam):
+            assert out["mog_visibility"].shape == self.model.density.shape
+            self.optimizer.step(out["mog_visibility"])
+        else:
+            self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         if self.schedule is not None:
             self._set_schedule_state(*self.schedule.after_optimizer_step(self.step_id))

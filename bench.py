@@ -387,16 +387,17 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
                 batch_for=batch_for, tracer=tracer, dev=dev)
 
 
-def run_drop_in(res, steps=8, warmup=3):
+def run_drop_in(res, steps=8, warmup=3, optimizer_type="adam"):
     """The SAME workload through the reference's own surface, untouched trainer side: Tracer.render -> Tracer._Autograd ->
     torch loss -> loss.backward() -> torch.optim.Adam (3dgrut_amd/train.TrainStep = trainer.py:705-778 with only the renderer
     swapped).  This is what a user of threedgrut.trainer gets by switching the plugin; `value` above additionally needs the
-    trainer to call the gut_optimize_* entry points."""
+    trainer to call the gut_optimize_* entry points.  optimizer_type "selective_adam": the reference's other
+    optimiser option (configs/base_gs.yaml:82, model.py:512) with ITS plugin swapped too (optimizers.SelectiveAdam)."""
     model_mod = importlib.import_module("3dgrut_amd.model")
     train_mod = importlib.import_module("3dgrut_amd.train")
     dev = res["dev"]
     model = model_mod.GaussianModel(res["scene"], device=dev, sh_degree=3)
-    stepper = train_mod.TrainStep(model, res["tracer"], scene_extent=res["extent"], world_size=1)
+    stepper = train_mod.TrainStep(model, res["tracer"], scene_extent=res["extent"], world_size=1, optimizer_type=optimizer_type)
     for s in range(warmup):
         stepper.step(res["batch_for"](s))
     torch.cuda.synchronize(dev)
@@ -407,6 +408,9 @@ def run_drop_in(res, steps=8, warmup=3):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     fb = res["tracer"].tracer_wrapper.collect_times()
+    if optimizer_type == "selective_adam":
+        return {"trainer": "autograd (Tracer.render -> _Autograd -> SelectiveAdam.step(mog_visibility)): optimizer.type=selective_adam, both plugins swapped",
+                "value": steps / dt, "unit": "images/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps, "warmup": warmup}
     return {"trainer": "autograd (Tracer.render -> _Autograd -> torch.optim.Adam(fused)), the reference's surface unchanged",
             "value": steps / dt, "unit": "images/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps, "warmup": warmup,
             "forward_render_ms": fb.get("forward_render"), "backward_render_ms": fb.get("backward_render")}
@@ -620,6 +624,10 @@ def main():
                 out["drop_in"] = run_drop_in(res)
             except Exception as e:
                 out["drop_in"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                out["drop_in"]["selective_adam"] = run_drop_in(res, optimizer_type="selective_adam")
+            except Exception as e:
+                out["drop_in"]["selective_adam"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and res.get("colmap"):
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "not run: the CPU legs are wired for the named workloads' orbit cameras, not for --colmap views"}

@@ -723,3 +723,37 @@ def test_overlap_probe_keeps_the_faster_optimiser_form(monkeypatch):
     assert p["done"] and len(p["on"]) == 4 and len(p["off"]) == 4 and p["ms_on"] > 0 and p["ms_off"] > 0
     assert st.overlap_optimizer == (p["ms_on"] <= p["ms_off"])
     assert np.isfinite(float(loss))
+
+
+def test_train_step_with_the_selective_adam_option():
+    """train.TrainStep(optimizer_type="selective_adam") = the reference's `optimizer.type: selective_adam` (model.py:512, trainer.py:
+    747-749): rows the view did not see keep parameters and moments bit for bit; rows it saw move, on the FIRST step (zero moments),
+    (1 - beta1) / sqrt(1 - beta2) = 3.1623 times as far as torch.optim.Adam moves them — the reference's SelectiveAdam has no bias
+    correction, Adam's first step is lr * sign(g)."""
+    train_mod = importlib.import_module("3dgrut_amd.train")
+    model_mod = importlib.import_module("3dgrut_amd.model")
+    sc = scenes.scene_c1(6000, 41)
+    W, H = 96, 72
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.0, 0.0, 0.0), (1, 0, 0)), fx=90.0)
+    b = to_batch(view, DEV)
+    b.rgb_gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(3)).to(DEV)
+    steppers = {}
+    for kind in ("adam", "selective_adam"):
+        model = model_mod.GaussianModel(sc, device=DEV, sh_degree=3)
+        steppers[kind] = train_mod.TrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, optimizer_type=kind, fused_adam=False)
+    start = {n: p.detach().clone() for n, p in steppers["adam"].model.named_parameters()}
+    outs = {k: st.step(b)[1] for k, st in steppers.items()}
+    vis = outs["selective_adam"]["mog_visibility"].bool().squeeze()
+    assert 100 < int(vis.sum()) < 6000
+    pa, ps = dict(steppers["adam"].model.named_parameters()), dict(steppers["selective_adam"].model.named_parameters())
+    for name, p0 in start.items():
+        assert torch.equal(ps[name][~vis], p0[~vis]), name
+        d_sel, d_adam = (ps[name][vis] - p0[vis]).double(), (pa[name][vis] - p0[vis]).double()
+        moved = d_adam.abs() > 1e-3 * d_adam.abs().max()          # (steps below the parameter's ulp say nothing about the ratio)
+        assert int(moved.sum()) > 100, name
+        ratio = d_sel[moved] / d_adam[moved]
+        assert float(((ratio - 0.1 / 0.001 ** 0.5).abs() < 2e-2).double().mean()) > 0.995, name
+        st = steppers["selective_adam"].optimizer.state[ps[name]]
+        assert not st["exp_avg"][~vis].any() and not st["exp_avg_sq"][~vis].any()
+    with pytest.raises(ValueError):
+        train_mod.TrainStep(steppers["adam"].model, gut.Tracer({"render": {}}), optimizer_type="lion")
