@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  # override: dev experiments only
 
-GUT_ABI_VERSION = 3   # include/gut_hip.h: bumped on every struct / array-length / signature change
+GUT_ABI_VERSION = 4   # include/gut_hip.h: bumped on every struct / array-length / signature change
 GUT_NUM_KERNEL_TIMERS = 11
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2
@@ -73,7 +73,8 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_photometric_workspace_bytes", "gut_photometric_loss", "gut_optimize_after_bwd", "gut_set_option",
            "gut_trace_bwd_ex", "gut_optimize_rows_without_gradient", "gut_compact_gradient_rows", "gut_scatter_gradient_records",
            "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation",
-           "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev", "gut_adam_unwalked_waves_ex", "gut_sync_moments", "gut_trace_fields", "gut_trace_bwd_fields", "gut_selective_adam")
+           "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev", "gut_adam_unwalked_waves_ex", "gut_sync_moments", "gut_trace_fields", "gut_trace_bwd_fields", "gut_selective_adam",
+           "gut_trace_model_fields", "gut_trace_bwd_model_fields")
 
 _lib = None
 
@@ -102,6 +103,10 @@ def load():
     lib.gut_trace_fields.argtypes = [vp, vp, u32, i32, u32, f_p, f_p, f_p, f_p, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera), f_p, f_p, f_p, f_p]
     lib.gut_trace_bwd_fields.argtypes = [vp, vp, u32, i32, u32, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera), f_p, f_p, f_p, f_p,
                                          f_p, f_p, f_p, f_p, f_p]
+    lib.gut_trace_model_fields.argtypes = [vp, vp, u32, i32, u32, f_p, f_p, f_p, f_p, f_p, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera),
+                                           f_p, f_p, f_p, f_p]
+    lib.gut_trace_bwd_model_fields.argtypes = [vp, vp, u32, i32, u32, i32, i32, f_p, f_p, C.POINTER(GutCamera), f_p, f_p, f_p, f_p,
+                                               f_p, f_p, f_p, f_p, f_p, f_p]
     lib.gut_collect_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.gut_get_stats.argtypes = [vp, C.POINTER(GutStats)]
     lib.gut_debug_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -402,11 +402,28 @@ void gut_destroy(gut_handle h) {
     delete h;
 }
 
+static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                          const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+                          const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                          float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+                          float* d_particle_visibility, const float* d_features_albedo);
+
 int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
               const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
               const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
               float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
               float* d_particle_visibility) {
+    return trace_fwd_impl(h, stream_, frame_number, num_active_features, num_particles, d_particle_density, d_particle_radiance, width,
+                          height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density, d_ray_hit_distance, d_ray_hit_count,
+                          d_particle_visibility, nullptr);
+}
+
+// d_features_albedo != NULL: d_particle_radiance is features_specular [N,45] (gut_trace_model_fields)
+static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                          const float* d_particle_density, const float* d_particle_radiance, int32_t width, int32_t height,
+                          const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                          float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+                          float* d_particle_visibility, const float* d_features_albedo) {
     (void)frame_number;
     if (!h) return fail("gut_trace: null handle");
     if (!camera || !d_ray_origin || !d_ray_direction || !d_ray_radiance_density || !d_ray_hit_distance || !d_ray_hit_count)
@@ -476,7 +493,7 @@ int gut_trace(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_ac
     gut::launch_project(s, v, h->consts, n, num_active_features, d_particle_density, d_particle_radiance,
                         h->tiles_count.as<uint32_t>(), h->proj_pos.as<float>(), h->conic_opacity.as<float>(),
                         h->extent.as<float>(), h->depth.as<float>(), h->feat.as<float>(), d_particle_visibility,
-                        h->counters.as<gut::Counters>());
+                        h->counters.as<gut::Counters>(), d_features_albedo);
     mark(1);
     static const bool early_after_project = getenv("GUT_EARLY_AFTER_PROJECT") != nullptr;  // tuning experiments only
     if (early_after_project) {
@@ -702,6 +719,59 @@ int gut_trace_bwd_fields(gut_handle h, void* stream_, uint32_t frame_number, int
     return trace_bwd_impl(h, stream_, frame_number, num_active_features, num_particles, h->packed12.as<float>(), d_particle_radiance, width,
                           height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density, d_ray_radiance_density_grad,
                           d_ray_hit_distance, d_ray_hit_distance_grad, d_positions_grad /* non-null marker */, d_particle_radiance_grad, 0u, f);
+}
+
+// gut_trace_fields / gut_trace_bwd_fields with the SH coefficients as the model's two tensors too (features_albedo [N,3],
+// features_specular [N,45]; model.py:68-75) instead of get_features()'s torch.cat: K1 reads the wave's [64,45] block directly
+// (only the rows of Gaussians that survived culling), K8 writes the two gradient tensors (LDS-transposed, coalesced).
+int gut_trace_model_fields(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                           const float* d_positions, const float* d_density, const float* d_rotation, const float* d_scale,
+                           const float* d_features_albedo, const float* d_features_specular, int32_t width, int32_t height,
+                           const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                           float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+                           float* d_particle_visibility) {
+    if (!h) return fail("gut_trace_model_fields: null handle");
+    if (num_particles && (!d_positions || !d_density || !d_rotation || !d_scale || !d_features_albedo || !d_features_specular))
+        return fail("gut_trace_model_fields: null particle buffers with %u particles", num_particles);
+    if ((((uintptr_t)d_rotation | (uintptr_t)d_features_specular) & 15u) != 0)
+        return fail("gut_trace_model_fields: the rotation and features_specular tensors must be 16-byte aligned");
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        DeviceGuard dev_guard;
+        HIP_TRY(dev_guard.set(h->device));
+        h->packed_valid = false;
+        HIP_TRY(h->packed12.ensure(sizeof(float) * 12 * (size_t)num_particles + 64));
+        gut::launch_pack_fields(static_cast<hipStream_t>(stream_), num_particles, d_positions, d_density, d_rotation, d_scale,
+                                h->packed12.as<float>());
+        HIP_TRY(hipGetLastError());
+    }
+    const int rc = trace_fwd_impl(h, stream_, frame_number, num_active_features, num_particles, h->packed12.as<float>(),
+                                  d_features_specular, width, height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density,
+                                  d_ray_hit_distance, d_ray_hit_count, d_particle_visibility,
+                                  num_particles ? d_features_albedo : nullptr);
+    if (rc == 0) h->packed_valid = true;
+    return rc;
+}
+
+int gut_trace_bwd_model_fields(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                               int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
+                               const GutCamera* camera, const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                               const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_positions_grad,
+                               float* d_density_grad, float* d_rotation_grad, float* d_scale_grad, float* d_features_albedo_grad,
+                               float* d_features_specular_grad) {
+    if (!h) return fail("gut_trace_bwd_model_fields: null handle");
+    if (!h->packed_valid) return fail("gut_trace_bwd_model_fields: no gut_trace_fields / gut_trace_model_fields forward on this handle");
+    if (num_particles && (!d_positions_grad || !d_density_grad || !d_rotation_grad || !d_scale_grad || !d_features_albedo_grad ||
+                          !d_features_specular_grad))
+        return fail("gut_trace_bwd_model_fields: null gradient buffers");
+    if ((((uintptr_t)d_rotation_grad | (uintptr_t)d_features_specular_grad) & 15u) != 0)
+        return fail("gut_trace_bwd_model_fields: the rotation and features_specular gradients must be 16-byte aligned");
+    gut::GradFields f;
+    f.pos = d_positions_grad; f.dns = d_density_grad; f.rot = d_rotation_grad; f.scl = d_scale_grad;
+    f.alb = d_features_albedo_grad; f.spec = d_features_specular_grad;
+    return trace_bwd_impl(h, stream_, frame_number, num_active_features, num_particles, h->packed12.as<float>(), nullptr, width,
+                          height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density, d_ray_radiance_density_grad,
+                          d_ray_hit_distance, d_ray_hit_distance_grad, d_positions_grad /* non-null markers */, d_features_specular_grad, 0u, f);
 }
 
 static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,

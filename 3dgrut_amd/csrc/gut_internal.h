@@ -72,7 +72,7 @@ struct LazyMoments {
 void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, int sh_degree,
                     const float* density12, const float* sph48, uint32_t* tiles_count, float* proj_pos,
                     float* conic_opacity, float* extent, float* depth, float* feat, float* visibility,
-                    Counters* counters);
+                    Counters* counters, const float* sph_albedo = nullptr /* non-null: sph48 is features_specular [N,45], this is features_albedo [N,3] */);
 void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* offset,
                    const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
                    uint64_t* keys, uint32_t* ids, uint32_t capacity);
@@ -86,6 +86,8 @@ struct GradFields {
     float* dns = nullptr;   // [N,1]
     float* rot = nullptr;   // [N,4] (16-byte aligned)
     float* scl = nullptr;   // [N,3]
+    float* alb = nullptr;   // [N,3]  } with spec: the SH gradient as the model's two feature tensors instead of [N,48]
+    float* spec = nullptr;  // [N,45] } (16-byte aligned)
 };
 void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_degree, const float* density12,
                         const uint32_t* tiles_count, const float* feat, float* grad16 /* rows read are left zero */,

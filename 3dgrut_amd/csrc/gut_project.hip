@@ -342,10 +342,13 @@ __device__ __forceinline__ int bcast(int v, int src_lane) { return __shfl(v, src
 
 // (launch bound of 5 waves per SIMD: the compiler's own choice is 124 VGPRs = 4 waves; at 92 VGPRs nothing spills and the
 //  kernel is 12 % faster, at 6 waves it spills and is 18 % slower)
-template <int kVariant, bool kRolling>
+// kSplitSH: the SH coefficients arrive as the model's two tensors (features_albedo [N,3] = the degree-0 triple, features_specular
+// [N,45]; threedgrut/model/model.py:68-75) instead of their [N,48] concatenation: `sph48` is then the [N,45] tensor.
+template <int kVariant, bool kRolling, bool kSplitSH>
 __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, RenderConsts c, uint32_t n, int sh_degree,
                                                             const float4* __restrict__ density12,
                                                             const float* __restrict__ sph48,
+                                                            const float* __restrict__ sph_albedo,
                                                             uint32_t* __restrict__ tiles_count, float2* __restrict__ proj_pos,
                                                             float4* __restrict__ conic_opacity, float2* __restrict__ extent,
                                                             float* __restrict__ depth, float* __restrict__ feat,
@@ -503,22 +506,77 @@ __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, Re
         }
         const int ncoef = (sh_degree + 1) * (sh_degree + 1);
         float4 shq[12];
+        float alb0 = 0.f, alb1 = 0.f, alb2 = 0.f;
+        if (kSplitSH) {
+            // the wave's block of the [N,45] tensor: 64 x 180 B = 720 float4, contiguous and 16-byte aligned (wave_first is a
+            // multiple of 64); a half (32 rows) is exactly 360 of them.  A float4 may straddle two rows: fetched if either is visible.
+            const float* spec = sph48 + (size_t)wave_first * 45;
+            const uint32_t lim = rows_here * 45u;  // floats of the block that exist (the tensor may end inside the last float4)
+            if (vis) {
+                alb0 = sph_albedo[3 * (size_t)i + 0];
+                alb1 = sph_albedo[3 * (size_t)i + 1];
+                alb2 = sph_albedo[3 * (size_t)i + 2];
+            }
 #pragma unroll
-        for (int it = 0; it < 12; ++it) {
-            const uint32_t q = (uint32_t)it * 64u + (uint32_t)lane;  // float4 index inside the 12 KiB block
-            // rows are 192 B = three whole 64-byte lines: rows of culled Gaussians are not fetched at all
-            const bool wanted = (q < rows_here * 12u) && ((vis_mask >> (q / 12u)) & 1ull);
-            shq[it] = wanted ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it = 0; it < 12; ++it) {
+                const uint32_t ql = (uint32_t)(it % 6) * 64u + (uint32_t)lane;
+                const uint32_t f = 4u * ((uint32_t)(it / 6) * 360u + ql);
+                const uint32_t r0 = min(f / 45u, 63u), r1 = min((f + 3u) / 45u, 63u);
+                const bool wanted = (ql < 360u) && (f < lim) && (sh_degree > 0) && (((vis_mask >> r0) | (vis_mask >> r1)) & 1ull);
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wanted) {
+                    if (f + 3u < lim) {
+                        val = *reinterpret_cast<const float4*>(spec + f);
+                    } else {
+                        val.x = spec[f];
+                        if (f + 1u < lim) val.y = spec[f + 1u];
+                        if (f + 2u < lim) val.z = spec[f + 2u];
+                    }
+                }
+                shq[it] = val;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const uint32_t q = (uint32_t)it * 64u + (uint32_t)lane;  // float4 index inside the 12 KiB block
+                // rows are 192 B = three whole 64-byte lines: rows of culled Gaussians are not fetched at all
+                const bool wanted = (q < rows_here * 12u) && ((vis_mask >> (q / 12u)) & 1ull);
+                shq[it] = wanted ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if (kSplitSH) {
+                // row r of the half -> LDS row r: [albedo(3) | specular(45)], the same 48 columns the concatenated tensor has
 #pragma unroll
-            for (int it6 = 0; it6 < 6; ++it6) {
-                const uint32_t q = (uint32_t)it6 * 64u + (uint32_t)lane;  // float4 index inside this half (32 rows)
-                const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
-                float* dst = wl + row * kShRow + col;
-                const float4 val = shq[half * 6 + it6];
-                dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+                for (int it6 = 0; it6 < 6; ++it6) {
+                    const uint32_t ql = (uint32_t)it6 * 64u + (uint32_t)lane;
+                    if (ql < 360u) {
+                        const uint32_t f = 4u * ql;
+                        const uint32_t row = f / 45u, col = f - row * 45u;
+                        const float4 val = shq[half * 6 + it6];
+                        const float vals[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; ++j) {
+                            const uint32_t cj = col + j;
+                            const uint32_t rj = cj >= 45u ? row + 1u : row;
+                            if (rj < 32u) wl[rj * kShRow + 3u + (cj >= 45u ? cj - 45u : cj)] = vals[j];
+                        }
+                    }
+                }
+                if ((lane >> 5) == half) {
+                    float* own = wl + (lane & 31) * kShRow;
+                    own[0] = alb0; own[1] = alb1; own[2] = alb2;
+                }
+            } else {
+#pragma unroll
+                for (int it6 = 0; it6 < 6; ++it6) {
+                    const uint32_t q = (uint32_t)it6 * 64u + (uint32_t)lane;  // float4 index inside this half (32 rows)
+                    const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
+                    float* dst = wl + row * kShRow + col;
+                    const float4 val = shq[half * 6 + it6];
+                    dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -714,20 +772,24 @@ __global__ __launch_bounds__(kBlock) void k_tile_ranges(uint32_t m, const uint64
 // kRawGrads: additionally chain d(position, density, quaternion, scale) through the model's activations
 // (sigmoid, normalise, exp — threedgrut/model/model.py:74-93) so that the rows can be fed to the optimiser as
 // gradients of the RAW parameters; |quat| is read from the pad column written by k_activate_pack.
-template <bool kRawGrads>
+// kSplitSH (with `fields` only): the SH gradient goes out as the model's two tensors, fields.alb [N,3] and fields.spec [N,45]
+// (model.py:68-75) — the wave's 64 x 45 block is transposed through LDS and written with coalesced 16-byte stores.
+template <bool kRawGrads, bool kSplitSH>
 __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint32_t n, int sh_degree,
                                                             const float4* __restrict__ density12,
                                                             const uint32_t* __restrict__ tiles_count,
                                                             const float* __restrict__ feat, float4* __restrict__ grad16,
                                                             float4* __restrict__ density_grad12,
                                                             float4* __restrict__ sph_grad48, GradFields fields) {
+    __shared__ __attribute__((aligned(16))) float spec_lds[kSplitSH ? (kBlock / 64) * 64 * 45 : 4];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    const bool live = i < n;
+    if (!kSplitSH && !live) return;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
     float out[48];
 #pragma unroll
     for (int k = 0; k < 48; ++k) out[k] = 0.0f;
-    if (tiles_count[i] != 0) {
+    if (live && tiles_count[i] != 0) {
         g0 = grad16[4 * (size_t)i + 0];
         g1 = grad16[4 * (size_t)i + 1];
         g2 = grad16[4 * (size_t)i + 2];
@@ -767,21 +829,54 @@ __global__ __launch_bounds__(kBlock) void k_project_backward(ViewParams v, uint3
                 out[3 * k + 2] = Y[k] * m2;
             }
     }
-    if (fields.pos) {
-        // the four gradient tensors the reference's _Autograd.backward hands back (tracer.py:268-286), written directly
-        // instead of one [N,12] tensor that torch then splits and copies four times
-        fields.pos[3 * (size_t)i + 0] = g0.x; fields.pos[3 * (size_t)i + 1] = g0.y; fields.pos[3 * (size_t)i + 2] = g0.z;
-        fields.dns[i] = g0.w;
-        reinterpret_cast<float4*>(fields.rot)[i] = g1;
-        fields.scl[3 * (size_t)i + 0] = g2.x; fields.scl[3 * (size_t)i + 1] = g2.y; fields.scl[3 * (size_t)i + 2] = g2.z;
-    } else {
-        density_grad12[3 * (size_t)i + 0] = g0;
-        density_grad12[3 * (size_t)i + 1] = g1;
-        density_grad12[3 * (size_t)i + 2] = g2;
+    if (live) {
+        if (fields.pos) {
+            // the four gradient tensors the reference's _Autograd.backward hands back (tracer.py:268-286), written directly
+            // instead of one [N,12] tensor that torch then splits and copies four times
+            fields.pos[3 * (size_t)i + 0] = g0.x; fields.pos[3 * (size_t)i + 1] = g0.y; fields.pos[3 * (size_t)i + 2] = g0.z;
+            fields.dns[i] = g0.w;
+            reinterpret_cast<float4*>(fields.rot)[i] = g1;
+            fields.scl[3 * (size_t)i + 0] = g2.x; fields.scl[3 * (size_t)i + 1] = g2.y; fields.scl[3 * (size_t)i + 2] = g2.z;
+        } else {
+            density_grad12[3 * (size_t)i + 0] = g0;
+            density_grad12[3 * (size_t)i + 1] = g1;
+            density_grad12[3 * (size_t)i + 2] = g2;
+        }
     }
+    if (kSplitSH) {
+        const int lane = (int)(threadIdx.x & 63);
+        const uint32_t wave_first = i - (uint32_t)lane;
+        const uint32_t rows_here = wave_first < n ? min(64u, n - wave_first) : 0u;
+        float* wl = spec_lds + (threadIdx.x >> 6) * (64 * 45);
+        if (live) {
+            fields.alb[3 * (size_t)i + 0] = out[0]; fields.alb[3 * (size_t)i + 1] = out[1]; fields.alb[3 * (size_t)i + 2] = out[2];
+        }
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
-        sph_grad48[12 * (size_t)i + k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+        for (int k = 0; k < 45; ++k) wl[lane * 45 + k] = out[3 + k];   // (stride 45 dwords: conflict-free)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* dst = fields.spec + (size_t)wave_first * 45;             // 16-byte aligned: wave_first is a multiple of 64
+        const uint32_t lim = rows_here * 45u;
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const uint32_t f = 4u * ((uint32_t)it * 64u + (uint32_t)lane);
+            if (f < 2880u && f < lim) {
+                const float4 val = *reinterpret_cast<const float4*>(wl + f);
+                if (f + 3u < lim) {
+                    *reinterpret_cast<float4*>(dst + f) = val;
+                } else {                                                 // the tensor ends inside this float4
+                    dst[f] = val.x;
+                    if (f + 1u < lim) dst[f + 1u] = val.y;
+                    if (f + 2u < lim) dst[f + 2u] = val.z;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            sph_grad48[12 * (size_t)i + k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+    }
 }
 
 // k_pack_fields: (positions [N,3], density [N,1], rotation [N,4], scale [N,3]) -> the [N,12] rows the kernels read
@@ -886,7 +981,7 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock
 void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, int sh_degree,
                     const float* density12, const float* sph48, uint32_t* tiles_count, float* proj_pos,
                     float* conic_opacity, float* extent, float* depth, float* feat, float* visibility,
-                    Counters* counters) {
+                    Counters* counters, const float* sph_albedo) {
     if (n == 0) return;
     bool distorted = false;
     for (float k : v.radial) distorted |= (k != 0.0f);
@@ -894,10 +989,13 @@ void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, u
     for (float k : v.thin_prism) distorted |= (k != 0.0f);
     const int variant = v.model == GUT_CAMERA_OPENCV_FISHEYE ? 2 : (distorted ? 1 : 0);
     const bool rolling = v.shutter != GUT_SHUTTER_GLOBAL;
-    auto kern = rolling ? (variant == 0 ? k_project_on_tiles<0, true> : (variant == 1 ? k_project_on_tiles<1, true> : k_project_on_tiles<2, true>))
-                        : (variant == 0 ? k_project_on_tiles<0, false> : (variant == 1 ? k_project_on_tiles<1, false> : k_project_on_tiles<2, false>));
+    auto kern = rolling ? (variant == 0 ? k_project_on_tiles<0, true, false> : (variant == 1 ? k_project_on_tiles<1, true, false> : k_project_on_tiles<2, true, false>))
+                        : (variant == 0 ? k_project_on_tiles<0, false, false> : (variant == 1 ? k_project_on_tiles<1, false, false> : k_project_on_tiles<2, false, false>));
+    if (sph_albedo)   // sph48 is the [N,45] specular tensor
+        kern = rolling ? (variant == 0 ? k_project_on_tiles<0, true, true> : (variant == 1 ? k_project_on_tiles<1, true, true> : k_project_on_tiles<2, true, true>))
+                       : (variant == 0 ? k_project_on_tiles<0, false, true> : (variant == 1 ? k_project_on_tiles<1, false, true> : k_project_on_tiles<2, false, true>));
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, sh_degree,
-                       reinterpret_cast<const float4*>(density12), sph48, tiles_count, reinterpret_cast<float2*>(proj_pos),
+                       reinterpret_cast<const float4*>(density12), sph48, sph_albedo, tiles_count, reinterpret_cast<float2*>(proj_pos),
                        reinterpret_cast<float4*>(conic_opacity), reinterpret_cast<float2*>(extent), depth, feat, visibility,
                        counters);
 }
@@ -921,7 +1019,8 @@ void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_d
                         const uint32_t* tiles_count, const float* feat, float* grad16, float* density_grad12,
                         float* sph_grad48, bool raw_grads, const GradFields& fields) {
     if (n == 0) return;
-    auto kern = raw_grads ? k_project_backward<true> : k_project_backward<false>;
+    auto kern = raw_grads ? k_project_backward<true, false> : k_project_backward<false, false>;
+    if (fields.spec) kern = k_project_backward<false, true>;   // (gut_trace_bwd_model_fields: activated-parameter gradients only)
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), tiles_count, feat,
                        reinterpret_cast<float4*>(grad16), reinterpret_cast<float4*>(density_grad12),

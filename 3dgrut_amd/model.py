@@ -37,6 +37,12 @@ class GaussianModel(torch.nn.Module):
     def get_density(self):
         return torch.sigmoid(self.density)
 
+    def get_features_albedo(self):      # model.py:68-72
+        return self.features_albedo
+
+    def get_features_specular(self):
+        return self.features_specular
+
     def get_features(self):
         return torch.cat((self.features_albedo, self.features_specular), dim=1)
 

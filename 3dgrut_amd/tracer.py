@@ -330,6 +330,69 @@ class SplatRaster:
         _capi.check(rc, "trace_bwd_fields")
         return pos_g, dns_g, rot_g, scl_g, sph_g
 
+    def trace_model_fields(self, frame_number, num_active_features, mog_pos, mog_dns, mog_rot, mog_scl, sph_albedo, sph_specular, ray_ori,
+                           ray_dir, sensor_params, ts_start, ts_end, pose_start, pose_end):
+        """trace_fields() with the SH coefficients as the model's two tensors (features_albedo [N,3], features_specular [N,45]; model.py:
+        68-75) instead of get_features()'s [N,48] torch.cat (gut_trace_model_fields)."""
+        ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
+        ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
+        if ray_ori.dim() != 4 or ray_ori.shape[0] != 1:
+            raise RuntimeError("[3dgut] rays must be [1,H,W,3] (the reference renders one view per call)")
+        H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
+        n = int(mog_pos.shape[0])
+        dev = ray_ori.device
+        if n:
+            mog_pos = _check_f32_cuda(mog_pos, "positions", (3,)); mog_dns = _check_f32_cuda(mog_dns, "density", (1,))
+            mog_rot = _check_f32_cuda(mog_rot, "rotation", (4,)); mog_scl = _check_f32_cuda(mog_scl, "scale", (3,))
+            sph_albedo = _check_f32_cuda(sph_albedo, "featuresAlbedo", (3,))
+            sph_specular = _check_f32_cuda(sph_specular, "featuresSpecular", (45,))
+            if sph_albedo.shape[0] != n or sph_specular.shape[0] != n:
+                raise RuntimeError("[3dgut] feature tensors and positions differ in their number of rows")
+        opts = dict(dtype=torch.float32, device=dev)
+        rgba, dist, hits, vis = torch.empty((H, W, 4), **opts), torch.empty((H, W, 1), **opts), torch.empty((H, W, 1), **opts), torch.empty((n, 1), **opts)
+        cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: t.data_ptr() if n else None
+        with torch.cuda.device(dev):
+            rc = self._lib.gut_trace_model_fields(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF, int(num_active_features), n,
+                                                  ptr(mog_pos), ptr(mog_dns), ptr(mog_rot), ptr(mog_scl), ptr(sph_albedo), ptr(sph_specular),
+                                                  W, H, ray_ori.data_ptr(), ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(),
+                                                  dist.data_ptr(), hits.data_ptr(), ptr(vis))
+        _capi.check(rc, "trace_model_fields")
+        return rgba, dist, hits, vis
+
+    def trace_bwd_model_fields(self, frame_number, num_active_features, num_particles, ray_ori, ray_dir, sensor_params, ts_start, ts_end,
+                               pose_start, pose_end, ray_radiance_density, ray_radiance_density_grd, ray_hit_distance, ray_hit_distance_grd,
+                               out=None):
+        """Backward of trace_model_fields: (positions, density, rotation, scale, features_albedo, features_specular) gradients as six
+        fresh tensors (or the six of `out`), each written in full by the kernels."""
+        ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
+        ray_dir = _check_f32_cuda(ray_dir, "rayDirection", (3,))
+        H, W = int(ray_ori.shape[1]), int(ray_ori.shape[2])
+        n = int(num_particles)
+        dev = ray_ori.device
+        rgba = _check_f32_cuda(ray_radiance_density, "rayRadianceDensity", (4,))
+        rgba_g = _check_f32_cuda(ray_radiance_density_grd, "rayRadianceDensityGradient", (4,))
+        dist = _check_f32_cuda(ray_hit_distance, "rayHitDistance")
+        dist_g = None if ray_hit_distance_grd is None else _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
+        opts = dict(dtype=torch.float32, device=dev)
+        if out is not None:
+            pos_g, dns_g, rot_g, scl_g, alb_g, spec_g = (_check_f32_cuda(t, "gradient output", (c,)) for t, c in zip(out, (3, 1, 4, 3, 3, 45)))
+            if any(t.shape[0] != n or not o.is_contiguous() for t, o in zip((pos_g, dns_g, rot_g, scl_g, alb_g, spec_g), out)):
+                raise RuntimeError("[3dgut] gradient outputs must be contiguous [N,c] tensors with the forward's number of rows")
+        else:
+            pos_g, dns_g, rot_g, scl_g, alb_g, spec_g = (torch.empty((n, c), **opts) for c in (3, 1, 4, 3, 3, 45))
+        cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ptr = lambda t: t.data_ptr() if n else None
+        with torch.cuda.device(dev):
+            rc = self._lib.gut_trace_bwd_model_fields(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF, int(num_active_features),
+                                                      n, W, H, ray_ori.data_ptr(), ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(),
+                                                      rgba_g.data_ptr(), dist.data_ptr(), None if dist_g is None else dist_g.data_ptr(),
+                                                      ptr(pos_g), ptr(dns_g), ptr(rot_g), ptr(scl_g), ptr(alb_g), ptr(spec_g))
+        _capi.check(rc, "trace_bwd_model_fields")
+        return pos_g, dns_g, rot_g, scl_g, alb_g, spec_g
+
     def optimize_after_bwd(self, num_active_features, camera_position, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps,
                            step, visibility=None, act_out=None, lazy=None):
         """Per-Gaussian backward epilogue + SH-gradient rebuild + Adam in one pass (gut_optimize_after_bwd); follows a
@@ -440,14 +503,29 @@ class Tracer:
     class _Autograd(torch.autograd.Function):
         @staticmethod
         def forward(ctx, tracer_wrapper, frame_id, n_active_features, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl,
-                    mog_dns, mog_sph, sensor_params, sensor_poses):
-            particle_radiance = mog_sph.contiguous()
+                    mog_dns, mog_sph, sensor_params, sensor_poses, mog_sph_specular=None):
+            """The reference's twelve arguments (tracer.py:161-174); a thirteenth, mog_sph_specular, says that mog_sph is the model's
+            features_albedo [N,3] and this its features_specular [N,45] (Tracer.render below, for models that expose the two)."""
             ctx.frame_id = frame_id
             ctx.n_active_features = n_active_features
             ctx.sensor_params = sensor_params
             ctx.sensor_poses = sensor_poses
             ctx.tracer_wrapper = tracer_wrapper
             ctx.set_materialize_grads(False)  # an unused pred_dist arrives as None -> backward variant without dist terms
+            ctx.model_fields = mog_sph_specular is not None
+            if ctx.model_fields:
+                # all six model tensors go to the library as they are (gut_trace_model_fields): no torch.cat of the features
+                # either (1.0 ms per render at 6 M Gaussians), and six gradient tensors come back, nothing for autograd to split
+                rgba, dist, hits, vis = tracer_wrapper.trace_model_fields(
+                    frame_id, n_active_features, mog_pos, mog_dns, mog_rot, mog_scl, mog_sph.contiguous(), mog_sph_specular.contiguous(),
+                    ray_ori.contiguous(), ray_dir.contiguous(), sensor_params, sensor_poses.timestamps_us[0],
+                    sensor_poses.timestamps_us[1], sensor_poses.T_world_sensors[0], sensor_poses.T_world_sensors[1])
+                ctx.fields = True
+                ctx.num_particles = int(mog_pos.shape[0])
+                ctx.save_for_backward(ray_ori, ray_dir, rgba, dist)
+                ctx.mark_non_differentiable(hits, vis)
+                return rgba, dist, hits, vis
+            particle_radiance = mog_sph.contiguous()
             ctx.fields = hasattr(tracer_wrapper, "trace_fields")
             if ctx.fields:
                 # this library's wrapper packs the [pos | density | quat | scale | 0] rows itself (gut_trace_fields) and returns the
@@ -475,6 +553,15 @@ class Tracer:
         @staticmethod
         def backward(ctx, rgba_grd, dist_grd, hits_grd_unused, vis_grd_unused):
             poses = ctx.sensor_poses
+            if ctx.model_fields:
+                ray_ori, ray_dir, rgba, dist = ctx.saved_tensors
+                if rgba_grd is None:
+                    rgba_grd = torch.zeros_like(rgba)
+                pos_g, dns_g, rot_g, scl_g, alb_g, spec_g = ctx.tracer_wrapper.trace_bwd_model_fields(
+                    ctx.frame_id, ctx.n_active_features, ctx.num_particles, ray_ori, ray_dir, ctx.sensor_params, poses.timestamps_us[0],
+                    poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_grd.contiguous(), dist,
+                    None if dist_grd is None else dist_grd.contiguous())
+                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, alb_g, None, None, spec_g)
             if ctx.fields:
                 ray_ori, ray_dir, rgba, dist, particle_radiance = ctx.saved_tensors
                 if rgba_grd is None:
@@ -483,7 +570,7 @@ class Tracer:
                     ctx.frame_id, ctx.n_active_features, ctx.num_particles, particle_radiance, ray_ori, ray_dir, ctx.sensor_params,
                     poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1], rgba,
                     rgba_grd.contiguous(), dist, None if dist_grd is None else dist_grd.contiguous())
-                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, sph_grd, None, None)
+                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, sph_grd, None, None, None)
             ray_ori, ray_dir, rgba, dist, particle_density, particle_radiance = ctx.saved_tensors
             if rgba_grd is None:
                 rgba_grd = torch.zeros_like(rgba)
@@ -493,13 +580,14 @@ class Tracer:
                 poses.T_world_sensors[1], rgba, rgba_grd.contiguous(), dist, None if dist_grd is None else dist_grd.contiguous())
             pos_g, dns_g, rot_g, scl_g, _ = torch.split(dens_grd, [3, 1, 4, 3, 1], dim=1)  # tracer.py:268-270
             return (None, None, None, None, None, pos_g.contiguous(), rot_g.contiguous(), scl_g.contiguous(),
-                    dns_g.contiguous(), sph_grd, None, None)
+                    dns_g.contiguous(), sph_grd, None, None, None)
 
     def __init__(self, conf):
         self.device = "cuda"
         self.conf = conf
         torch.zeros(1, device=self.device)  # force context creation (tracer.py:292)
         self.tracer_wrapper = SplatRaster(conf)
+        self.split_features = True   # False: always go through gaussians.get_features() (the reference's call, kept for A/B tests)
 
     @property
     def timings(self):
@@ -512,10 +600,17 @@ class Tracer:
         rays_o = gpu_batch.rays_ori
         rays_d = gpu_batch.rays_dir
         sensor, poses = Tracer.create_camera_parameters(gpu_batch)
+        if (self.split_features and hasattr(self.tracer_wrapper, "trace_model_fields")
+                and hasattr(gaussians, "get_features_albedo") and hasattr(gaussians, "get_features_specular")):
+            # the reference's model keeps the SH coefficients as two tensors and concatenates them for every render (model.py:74-75):
+            # hand the two over as they are (the only difference from tracer.py:317-327)
+            features = (gaussians.get_features_albedo().contiguous(), sensor, poses, gaussians.get_features_specular().contiguous())
+        else:
+            features = (gaussians.get_features().contiguous(), sensor, poses)
         pred_rgba, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
             self.tracer_wrapper, frame_id, gaussians.n_active_features, rays_o.contiguous(), rays_d.contiguous(),
             gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
-            gaussians.get_density().contiguous(), gaussians.get_features().contiguous(), sensor, poses)
+            gaussians.get_density().contiguous(), *features)
         pred_rgb = pred_rgba[..., :3].unsqueeze(0).contiguous()
         pred_opacity = pred_rgba[..., 3:].unsqueeze(0).contiguous()
         pred_dist = pred_dist.unsqueeze(0).contiguous()

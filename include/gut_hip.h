@@ -30,8 +30,9 @@ extern "C" {
 
 /* Bumped on every change of a struct layout, an array length or an entry point's signature (2: GutStats grew to 80 bytes and
  * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: GutLazyMoments in the gut_optimize_* / gut_sh_adam_step_ex signatures, gut_sync_moments,
- * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev, gut_trace_fields / gut_trace_bwd_fields). */
-#define GUT_ABI_VERSION 3
+ * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev, gut_trace_fields / gut_trace_bwd_fields;
+ * 4: gut_trace_model_fields / gut_trace_bwd_model_fields). */
+#define GUT_ABI_VERSION 4
 
 typedef struct gut_context* gut_handle;
 
@@ -192,6 +193,27 @@ int gut_trace_bwd_fields(gut_handle h, void* stream, uint32_t frame_number, int3
                          const float* d_ray_radiance_density_grad, const float* d_ray_hit_distance,
                          const float* d_ray_hit_distance_grad, float* d_positions_grad, float* d_density_grad, float* d_rotation_grad,
                          float* d_scale_grad, float* d_particle_radiance_grad);
+
+/* gut_trace_fields / gut_trace_bwd_fields with the SH coefficients handed over as the model's TWO feature tensors as well
+ * (features_albedo [N,3] = the degree-0 triple, features_specular [N,45]; threedgrut/model/model.py:68-75), instead of the [N,48]
+ * tensor `get_features()` builds with torch.cat for every render (threedgut_tracer/tracer.py:322) — a 2.3 GB copy at 6 M
+ * Gaussians, plus the split and two copies autograd makes of its gradient.  The projection reads each wave's [64,45] block
+ * directly (rows of culled Gaussians are not fetched); the backward writes the two gradient tensors in full (zeros for Gaussians
+ * without tiles), coalesced.  Results are those of gut_trace_fields on the concatenation, bit for bit.  d_rotation,
+ * d_features_specular and their gradients must be 16-byte aligned.  The backward follows a gut_trace_model_fields (or
+ * gut_trace_fields) forward on the same handle and stream. */
+int gut_trace_model_fields(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                           const float* d_positions, const float* d_density, const float* d_rotation, const float* d_scale,
+                           const float* d_features_albedo, const float* d_features_specular, int32_t width, int32_t height,
+                           const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                           float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+                           float* d_particle_visibility);
+int gut_trace_bwd_model_fields(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                               int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
+                               const GutCamera* camera, const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
+                               const float* d_ray_hit_distance, const float* d_ray_hit_distance_grad, float* d_positions_grad,
+                               float* d_density_grad, float* d_rotation_grad, float* d_scale_grad, float* d_features_albedo_grad,
+                               float* d_features_specular_grad);
 
 /* SplatRaster::collectTimes — splatRaster.cpp:334-364: mean ms per tag over the timers recorded
  * since the last call; -1 for a tag with no samples. */

@@ -551,3 +551,86 @@ def test_field_wise_trace_equals_the_packed_trace():
     b.trace(0, 3, d12, sph, ro, rd, None, sensor, ts[0], ts[1], ps[0], ps[1])
     with pytest.raises(RuntimeError, match="no gut_trace_fields forward"):
         b.trace_bwd_fields(0, 3, pos.shape[0], sph, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1], out_b[0], g, out_b[1], dg)
+
+
+@pytest.mark.parametrize("n,degree", [(1000, 3), (1001, 3), (1002, 2), (1003, 1), (1000, 0), (63, 3), (1, 3)])
+def test_model_field_trace_equals_the_field_wise_trace(n, degree):
+    """gut_trace_model_fields / gut_trace_bwd_model_fields (the SH coefficients as the model's features_albedo [N,3] and
+    features_specular [N,45] instead of their torch.cat) against gut_trace_fields on the concatenation: forward outputs and integer
+    buffers bit-identical, gradients equal up to the float-atomic order with the same entries exactly zero.  Row counts whose
+    [N,45] tensor ends inside a 16-byte word (N mod 4 != 0), a partial last wave, one wave, one row; the words behind both
+    [N,45] tensors are sentinels the kernels must neither use nor overwrite."""
+    mk, kind, W, H, (eye, tgt), kw = CASES["c1_pinhole_128"]
+    sc = {k: (v[:n] if isinstance(v, np.ndarray) and v.shape[:1] == (1000,) else v) for k, v in mk().items()}
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    model = gut_model(sc, 3)
+    with torch.no_grad():
+        pos, dns, rot, scl = model.positions.detach(), model.get_density(), model.get_rotation(), model.get_scale()
+        sph = model.get_features().contiguous()
+        alb = model.features_albedo.detach().contiguous()
+        spec_buf = torch.full((n * 45 + 16,), float("nan"), device=DEV)
+        spec = spec_buf[: n * 45].view(n, 45)
+        spec.copy_(model.features_specular.detach())
+    batch = to_batch(view, DEV)
+    sensor, poses = gut.Tracer.create_camera_parameters(batch)
+    ts, ps = poses.timestamps_us, poses.T_world_sensors
+    a, b = gut.Tracer({"render": {}}).tracer_wrapper, gut.Tracer({"render": {}}).tracer_wrapper
+    ro, rd = batch.rays_ori.contiguous(), batch.rays_dir.contiguous()
+    out_a = a.trace_fields(0, degree, pos, dns, rot, scl, sph, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1])
+    out_b = b.trace_model_fields(0, degree, pos, dns, rot, scl, alb, spec, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1])
+    for x, y in zip(out_a, out_b):
+        assert torch.equal(x, y)
+    for key in ("tiles_count", "sorted_ids", "sorted_keys", "tile_ranges"):
+        assert torch.equal(a.debug_buffer(key), b.debug_buffer(key)), key
+    assert torch.equal(a.debug_buffer("feat"), b.debug_buffer("feat"))       # the view-dependent colours K1 made of the coefficients
+    g = torch.randn((H, W, 4), generator=torch.Generator().manual_seed(3)).to(DEV)
+    dg = 0.1 * torch.randn((H, W, 1), generator=torch.Generator().manual_seed(4)).to(DEV)
+    pg, ng, rg, sg, fg = a.trace_bwd_fields(0, degree, n, sph, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1], out_a[0], g, out_a[1], dg)
+    spec_g_buf = torch.full((n * 45 + 16,), 7.0, device=DEV)
+    outs = [torch.empty((n, c), device=DEV) for c in (3, 1, 4, 3, 3)] + [spec_g_buf[: n * 45].view(n, 45)]
+    got = b.trace_bwd_model_fields(0, degree, n, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1], out_b[0], g, out_b[1], dg, out=outs)
+    assert bool((spec_g_buf[n * 45:] == 7.0).all())                       # nothing written behind the tensor
+    assert got[5].data_ptr() == spec_g_buf.data_ptr()
+    if n >= 1000:
+        assert int((fg != 0).any(dim=1).sum()) > 100
+    for name, x, ref in (("pos", got[0], pg), ("dns", got[1], ng), ("rot", got[2], rg), ("scl", got[3], sg), ("alb", got[4], fg[:, :3]),
+                         ("spec", got[5], fg[:, 3:])):
+        assert x.shape == ref.shape, name
+        assert torch.equal(x == 0, ref == 0), name
+        assert bool(torch.isfinite(x).all()), name
+        if float(ref.abs().max()) > 0:
+            assert rel_l2(x.cpu().numpy(), ref.contiguous().cpu().numpy()) <= 1e-5, name
+    if degree == 0:
+        assert not bool(got[5].any())
+    # a plain trace() on the handle invalidates the packed rows
+    d12 = torch.cat([pos, dns, rot, scl, torch.zeros_like(dns)], 1).contiguous()
+    b.trace(0, degree, d12, sph, ro, rd, None, sensor, ts[0], ts[1], ps[0], ps[1])
+    with pytest.raises(RuntimeError, match="forward on this handle"):
+        b.trace_bwd_model_fields(0, degree, n, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1], out_b[0], g, out_b[1], dg)
+
+
+@pytest.mark.parametrize("case", ["c1_pinhole_128", "fisheye_144x96"])
+def test_render_with_the_models_two_feature_tensors(case):
+    """Tracer.render on a model that exposes get_features_albedo / get_features_specular (the reference's MixtureOfGaussians does,
+    model.py:68-72) goes through gut_trace_model_fields; with tracer.split_features = False through get_features() and its torch.cat:
+    same image bit for bit, same parameter gradients up to the float-atomic order."""
+    mk, kind, W, H, (eye, tgt), kw = CASES[case]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    batch = to_batch(view, DEV)
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(6)).to(DEV)
+    grads, images = [], []
+    for split in (True, False):
+        model = gut_model(sc, 3)
+        tracer = gut.Tracer({"render": {}})
+        tracer.split_features = split
+        out = tracer.render(model, batch, train=True)
+        (out["pred_rgb"] - gt).abs().mean().backward()
+        images.append(out["pred_rgb"].detach())
+        grads.append({k: p.grad.detach() for k, p in model.named_parameters()})
+    assert torch.equal(images[0], images[1])
+    assert set(grads[0]) == set(grads[1]) and "features_specular" in grads[0]
+    for k in grads[0]:
+        assert grads[0][k].shape == grads[1][k].shape, k
+        assert torch.equal(grads[0][k] == 0, grads[1][k] == 0), k
+        assert rel_l2(grads[0][k].cpu().numpy(), grads[1][k].cpu().numpy()) <= 1e-5, k
