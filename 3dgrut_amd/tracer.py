@@ -600,7 +600,7 @@ class Tracer:
         rays_o = gpu_batch.rays_ori
         rays_d = gpu_batch.rays_dir
         sensor, poses = Tracer.create_camera_parameters(gpu_batch)
-        if (self.split_features and hasattr(self.tracer_wrapper, "trace_model_fields")
+        if (getattr(self, "split_features", True) and hasattr(self.tracer_wrapper, "trace_model_fields")
                 and hasattr(gaussians, "get_features_albedo") and hasattr(gaussians, "get_features_specular")):
             # the reference's model keeps the SH coefficients as two tensors and concatenates them for every render (model.py:74-75):
             # hand the two over as they are (the only difference from tracer.py:317-327)

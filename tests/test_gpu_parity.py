@@ -561,7 +561,7 @@ def test_model_field_trace_equals_the_field_wise_trace(n, degree):
     [N,45] tensor ends inside a 16-byte word (N mod 4 != 0), a partial last wave, one wave, one row; the words behind both
     [N,45] tensors are sentinels the kernels must neither use nor overwrite."""
     mk, kind, W, H, (eye, tgt), kw = CASES["c1_pinhole_128"]
-    sc = {k: (v[:n] if isinstance(v, np.ndarray) and v.shape[:1] == (1000,) else v) for k, v in mk().items()}
+    sc = scenes.scene_c1(n, 0) if n >= 1000 else {k: v[:n] for k, v in mk().items()}
     view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
     model = gut_model(sc, 3)
     with torch.no_grad():
