@@ -242,17 +242,45 @@ class GSStrategy:
         self.ops.s.v12[:, 3] = 0
 
 
+# configs/strategy/mcmc.yaml: (start_iteration, end_iteration, frequency) of each operation
+MCMC_SCHEDULE = dict(relocate=(500, 25000, 100), add=(500, 25000, 100), perturb=(0, 27500, 1))
+
+
 class MCMCStrategy:
-    def __init__(self, stepper, opacity_threshold=0.005, binom_n_max=51, max_n_gaussians=1_000_000, noise_lr=5e5, seed=0):
+    """threedgrut/strategy/mcmc.py:48-197 on the native trainer's state.  Three things come from outside the host logic and can be
+    replaced (the reference pins of tests/test_cpu_reference_pins.py feed the recorded ones): `sample_fn(weights, n, step)` —
+    the multinomial draw (default: torch.multinomial / the device-side inverse-CDF draw above, seeded per step);
+    `relocation_fn(opacities, scales, ratios)` — the relocation kernel (default: gut_mcmc_relocation, HIP, no CPU path);
+    `unit_normal_fn(shape, step)` — the standard-normal draws of the perturbation."""
+
+    def __init__(self, stepper, opacity_threshold=0.005, binom_n_max=51, max_n_gaussians=1_000_000, noise_lr=5e5, seed=0, schedule=None):
         self.ops = _StateOps(stepper)
         self.opacity_threshold, self.n_max, self.max_n, self.noise_lr, self.seed = opacity_threshold, binom_n_max, max_n_gaussians, noise_lr, seed
+        self.schedule = dict(MCMC_SCHEDULE, **(schedule or {}))
+        self.sample_fn = self.relocation_fn = self.unit_normal_fn = None
         b = torch.zeros((binom_n_max, binom_n_max), dtype=torch.float32)
         for n in range(binom_n_max):
             for k in range(n + 1):
                 b[n, k] = math.comb(n, k)
         self.binoms = b.to(self.ops.m.raw.device)
 
+    def post_optimizer_step(self, step, position_lr):
+        """mcmc.py:76-90: relocate, add, perturb — each on the iterations its (start, end, frequency) selects."""
+        from .schedule import check_step_condition
+        done = []
+        if check_step_condition(step, *self.schedule["relocate"]):
+            self.relocate(step); done.append("relocate")
+        if check_step_condition(step, *self.schedule["add"]):
+            self.add_new(step); done.append("add")
+        if check_step_condition(step, *self.schedule["perturb"]):
+            self.perturb(position_lr, step); done.append("perturb")
+        return done
+
     def _relocation(self, dens, scales, ratios):
+        if self.relocation_fn is not None:
+            return self.relocation_fn(dens, scales, ratios)
+        if not dens.is_cuda:
+            raise RuntimeError("[3dgut] MCMC relocation: the kernel is HIP only (there is no CPU path)")
         lib = _capi.load()
         new_d, new_s = torch.empty_like(dens), torch.empty_like(scales)
         st = torch.cuda.current_stream(dens.device).cuda_stream
@@ -266,12 +294,15 @@ class MCMCStrategy:
     def sample_new(self, num, valid_idx=None, step=0):
         """mcmc.py:166-197"""
         m = self.ops.m
-        dens = torch.sigmoid(m.raw[:, 3])
-        scales = torch.exp(m.raw[:, SCL])
+        dens = torch.sigmoid(m.raw[:, 3].contiguous())   # (contiguous: the CPU's vectorised and strided sigmoid / exp differ in the last bit)
+        scales = torch.exp(m.raw[:, SCL].contiguous())
         if valid_idx is None:
             valid_idx = torch.arange(dens.shape[0], device=dens.device)
-        gen = torch.Generator(device=dens.device).manual_seed(self.seed * 1_000_003 + step)
-        sampled = valid_idx[multinomial_sample(dens[valid_idx], num, gen)]
+        if self.sample_fn is not None:
+            drawn = self.sample_fn(dens[valid_idx], num, step)
+        else:
+            drawn = multinomial_sample(dens[valid_idx], num, torch.Generator(device=dens.device).manual_seed(self.seed * 1_000_003 + step))
+        sampled = valid_idx[drawn]
         ratios = (torch.bincount(sampled, minlength=dens.shape[0])[sampled] + 1).clamp_(min=1, max=self.n_max).int()
         new_d, new_s = self._relocation(dens[sampled].contiguous(), scales[sampled].contiguous(), ratios.contiguous())
         new_d = new_d.clamp(max=1.0 - torch.finfo(torch.float32).eps, min=self.opacity_threshold)
@@ -280,7 +311,7 @@ class MCMCStrategy:
     @torch.no_grad()
     def relocate(self, step=0):
         m, s = self.ops.m, self.ops.s
-        dens = torch.sigmoid(m.raw[:, 3])
+        dens = torch.sigmoid(m.raw[:, 3].contiguous())
         dead = torch.where(dens <= self.opacity_threshold)[0]
         alive = torch.where(dens > self.opacity_threshold)[0]
         if dead.numel() and alive.numel():
@@ -309,9 +340,13 @@ class MCMCStrategy:
     def perturb(self, position_lr, step=0):
         m = self.ops.m
         R = _quat_to_rotmat(m.raw[:, ROT])
-        S = torch.diag_embed(torch.exp(m.raw[:, SCL]))
+        S = torch.diag_embed(torch.exp(m.raw[:, SCL].contiguous()))
         cov = R @ S @ S.transpose(1, 2) @ R.transpose(1, 2)
-        dens = torch.sigmoid(m.raw[:, 3:4])
-        gen = torch.Generator(device=m.raw.device).manual_seed(self.seed * 1_000_003 + step + 7)
-        noise = torch.randn(m.raw[:, POS].shape, generator=gen, device=m.raw.device) * (1 / (1 + torch.exp(-100 * ((1 - dens) - 0.995)))) * self.noise_lr * position_lr
+        dens = torch.sigmoid(m.raw[:, 3:4].contiguous())
+        if self.unit_normal_fn is not None:
+            unit = self.unit_normal_fn(m.raw[:, POS].shape, step)
+        else:
+            gen = torch.Generator(device=m.raw.device).manual_seed(self.seed * 1_000_003 + step + 7)
+            unit = torch.randn(m.raw[:, POS].shape, generator=gen, device=m.raw.device)
+        noise = unit * (1 / (1 + torch.exp(-100 * ((1 - dens) - 0.995)))) * self.noise_lr * position_lr
         m.raw[:, POS] += torch.bmm(cov, noise.unsqueeze(-1)).squeeze(-1)

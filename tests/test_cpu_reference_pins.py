@@ -417,3 +417,81 @@ def test_gs_schedule_against_the_reference():
         assert mine == S[key].tolist(), name
     assert [s for s in range(20) if schedule.check_step_condition(s, 0, sc["densify"][1], 1)] == S["schedule_buffer"].tolist()
     assert not any(schedule.check_step_condition(s, *sc["density_decay"]) for s in range(16001))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N3: strategy.MCMCStrategy against threedgrut/strategy/mcmc.py itself (tests/golden/gen_mcmc_golden.py drove the reference's
+# MCMCStrategy on a fake MixtureOfGaussians with a real torch.optim.Adam; the multinomial draws, the relocation kernel's inputs
+# AND outputs (closed form in float64 — the CUDA plugin cannot exist here) and the perturbation's normal draws are recorded).
+# Same state, same draws, same kernel outputs -> same rows and moments after relocate / add / perturb.
+# ---------------------------------------------------------------------------------------------------------------------
+def _assert_mcmc_stage(S, tag, st, exact=True, skip=()):
+    cmp_ = (lambda a, b, what: np.testing.assert_array_equal(a, b, err_msg=what)) if exact else \
+        (lambda a, b, what: np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7, err_msg=what))
+    for src, suffix in ((st.model.raw, ""), (st.m12, "/exp_avg"), (st.v12, "/exp_avg_sq")):
+        for k, sl in (("positions", slice(0, 3)), ("density", slice(3, 4)), ("rotation", slice(4, 8)), ("scale", slice(8, 11))):
+            if (k + suffix) not in skip:
+                cmp_(src[:, sl].numpy(), S[f"{tag}/{k}{suffix}"], f"{tag}/{k}{suffix}")
+    for src, suffix in ((st.model.features, ""), (st.m48, "/exp_avg"), (st.v48, "/exp_avg_sq")):
+        cmp_(src[:, 0:3].numpy(), S[f"{tag}/features_albedo{suffix}"], f"{tag}/features_albedo{suffix}")
+        cmp_(src[:, 3:].numpy(), S[f"{tag}/features_specular{suffix}"], f"{tag}/features_specular{suffix}")
+
+
+def test_mcmc_strategy_against_the_reference():
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    S = np.load(os.path.join(GOLD, "mcmc_golden.npz"))
+    st = _StrategyStepper(S, "start")
+    mc = strategy.MCMCStrategy(st, opacity_threshold=0.005, binom_n_max=51, max_n_gaussians=330, noise_lr=500000.0)
+    np.testing.assert_array_equal(mc.binoms.numpy(), S["binoms"])        # the Pascal table handed to the kernel
+    calls = dict(sample=0, kernel=0)
+
+    def sample(weights, n, step):
+        i = calls["sample"]; calls["sample"] += 1
+        np.testing.assert_array_equal(weights.numpy(), S[f"sample{i}/probabilities"], err_msg=f"sample {i}: weights")
+        assert n == S[f"sample{i}/indices"].shape[0]
+        return torch.as_tensor(S[f"sample{i}/indices"])
+
+    def kernel(dens, scales, ratios):
+        i = calls["kernel"]; calls["kernel"] += 1
+        np.testing.assert_array_equal(dens.numpy().reshape(-1), S[f"kernel{i}/opacities"].reshape(-1), err_msg=f"kernel {i}: opacities")
+        np.testing.assert_array_equal(scales.numpy(), S[f"kernel{i}/scales"], err_msg=f"kernel {i}: scales")
+        np.testing.assert_array_equal(ratios.numpy(), S[f"kernel{i}/ratios"], err_msg=f"kernel {i}: ratios")
+        assert ratios.dtype == torch.int32 and dens.is_contiguous() and scales.is_contiguous()
+        return torch.as_tensor(S[f"kernel{i}/new_opacities"]).reshape(dens.shape), torch.as_tensor(S[f"kernel{i}/new_scales"])
+
+    mc.sample_fn, mc.relocation_fn = sample, kernel
+    mc.unit_normal_fn = lambda shape, step: torch.as_tensor(S["perturb/unit_draws"]).reshape(shape)
+
+    assert mc.relocate() == int(S["n_dead"]) > 0
+    _assert_mcmc_stage(S, "after_relocate", st)
+    assert mc.add_new() == 15 and st.model.raw.shape[0] == 315
+    _assert_mcmc_stage(S, "after_add", st)
+    mc.perturb(float(S["position_lr"]))
+    # positions: covariance @ noise with R from torch.nn.functional.normalize here, the reference's quaternion_to_so3 there
+    _assert_mcmc_stage(S, "after_perturb", st, skip=("positions",))
+    np.testing.assert_allclose(st.model.raw[:, 0:3].numpy(), S["after_perturb/positions"], rtol=2e-5, atol=1e-7)
+    moved = np.abs(S["after_perturb/positions"] - S["after_add/positions"]).max(axis=1)
+    assert (moved > 0).sum() > 10                                            # (the noise is gated to near-transparent Gaussians)
+    st.model.raw[:, 0:3] = torch.as_tensor(S["after_perturb/positions"])     # continue from the reference's bits
+    assert mc.add_new() == 15 and mc.add_new() == 0                          # 330 = the cap: nothing more, and no kernel call
+    _assert_mcmc_stage(S, "after_cap", st)
+    assert calls["kernel"] == int(S["kernel_calls"]) and calls["sample"] == int(S["sample_calls"])
+
+
+def test_mcmc_schedule_against_the_reference():
+    """post_optimizer_step fires relocate / add / perturb on exactly the iterations the reference's check_step_condition selects for
+    configs/strategy/mcmc.yaml (fixture: the selected iterations 0..28000), in the reference's order."""
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    S = np.load(os.path.join(GOLD, "mcmc_golden.npz"))
+    for name in ("relocate", "add", "perturb"):
+        mine = [s for s in range(28001) if schedule.check_step_condition(s, *strategy.MCMC_SCHEDULE[name])]
+        assert mine == S[f"schedule_{name}"].tolist(), name
+    st = _StrategyStepper(S, "start")
+    mc = strategy.MCMCStrategy(st)
+    log = []
+    mc.relocate = lambda step=0: log.append("relocate")
+    mc.add_new = lambda step=0: log.append("add")
+    mc.perturb = lambda lr, step=0: log.append("perturb")
+    assert mc.post_optimizer_step(600, 1e-4) == ["relocate", "add", "perturb"] == log
+    assert mc.post_optimizer_step(601, 1e-4) == ["perturb"] and mc.post_optimizer_step(500, 1e-4) == ["perturb"]
+    assert mc.post_optimizer_step(0, 1e-4) == [] and mc.post_optimizer_step(27500, 1e-4) == []

@@ -4,6 +4,7 @@ Tolerances: parameters after a step agree to rel-L2 1e-5 (fp32, different exp/si
 fused Adam alone matches torch.optim.Adam to 1e-6."""
 import ctypes as C
 import importlib
+import math
 
 import numpy as np
 import pytest
@@ -175,6 +176,55 @@ def test_mcmc_relocation_kernel_matches_formula():
     assert mc.relocate(step=1) == 40 and float(torch.sigmoid(mn.raw[:, 3]).min()) > 0.004
     n0 = mn.num_gaussians
     assert mc.add_new(step=2) == int(1.05 * n0) - n0 and mn.num_gaussians == int(1.05 * n0)
+
+
+def test_mcmc_relocation_kernel_on_what_the_reference_hands_it():
+    """gut_mcmc_relocation on the tensors the reference's MCMCStrategy handed to ITS kernel in tests/golden/mcmc_golden.npz (three
+    calls: a relocation and two additions; ratios up to the draws' multiplicity) against the recorded outputs — the kernel's
+    closed form (gaussian_mcmc.cu:33-73) in float64, rounded to float32."""
+    import os
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "mcmc_golden.npz"))
+    mn = native.NativeGaussianModel(scenes.scene_c1(64, 2), device=DEV)
+    mc = strategy.MCMCStrategy(native.NativeTrainStep(mn, gut.Tracer({"render": {}})), binom_n_max=51)
+    assert np.array_equal(mc.binoms.cpu().numpy(), S["binoms"])
+    for i in range(int(S["kernel_calls"])):
+        dens = torch.as_tensor(S[f"kernel{i}/opacities"]).reshape(-1).to(DEV)
+        nd, ns = mc._relocation(dens, torch.as_tensor(S[f"kernel{i}/scales"]).to(DEV), torch.as_tensor(S[f"kernel{i}/ratios"]).to(DEV))
+        np.testing.assert_allclose(nd.cpu().numpy(), S[f"kernel{i}/new_opacities"].reshape(-1), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(ns.cpu().numpy(), S[f"kernel{i}/new_scales"], rtol=2e-4, atol=1e-9)
+    assert max(int(S[f"kernel{i}/ratios"].max()) for i in range(3)) >= 3
+
+
+def test_mcmc_strategy_on_the_live_trainer():
+    """post_optimizer_step (mcmc.py:76-90) between native train steps, with the lazily decayed moments on: at an iteration the
+    schedule selects for all three operations the dead Gaussians are relocated, 5 % are added (new rows: zero moments) and the
+    near-transparent ones are perturbed; the trainer keeps stepping on the grown state and stays finite; at other iterations only
+    the perturbation runs."""
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    sc = scenes.scene_c1(4000, 12)
+    W, H = 96, 72
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.0, 0.0, 0.0), (1, 0, 0)), fx=90.0)
+    b = to_batch(view, DEV); b.T_to_world = b.T_to_world.cpu()
+    b.rgb_gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(3)).to(DEV)
+    model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+    st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, overlap_optimizer=True)
+    mc = strategy.MCMCStrategy(st, max_n_gaussians=4300, schedule=dict(relocate=(2, 100, 3), add=(2, 100, 3), perturb=(0, 100, 1)))
+    for _ in range(3):
+        st.step(b)
+    model.raw[100:160, 3] = -9.0                                  # sixty dead Gaussians
+    pos0 = model.raw[:, 0:3].clone()
+    assert mc.post_optimizer_step(3, 1.6e-4) == ["relocate", "add", "perturb"]
+    assert model.num_gaussians == 4200 and st.m48.shape[0] == 4200 and float(torch.sigmoid(model.raw[:, 3]).min()) > 0.004
+    assert not bool(st.m12[4000:].any()) and not bool(st.v48[4000:].any())
+    assert bool((model.raw[:4000, 0:3] != pos0).any())
+    for k in range(4, 9):
+        loss, _ = st.step(b)
+        done = mc.post_optimizer_step(k, 1.6e-4)
+        assert done == (["relocate", "add", "perturb"] if k == 6 else ["perturb"])
+    assert model.num_gaussians == 4300                              # the cap
+    st.sync_moments()
+    assert all(bool(torch.isfinite(t).all()) for t in (model.raw, model.features, st.m12, st.v12, st.m48, st.v48)) and math.isfinite(float(loss))
 
 
 def test_colmap_scene_trains_end_to_end(tmp_path):
