@@ -304,6 +304,11 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
             synthetic_optimizer_state(stepper)
         if model.num_gaussians >= 1_000_000 and not getattr(args, "no_placement_tuning", False):
             stepper.tune_placement()   # re-places the three [N,48] state tensors where that makes the optimiser's stream faster
+        if getattr(args, "densification_statistics", False):
+            # the first half of a reference run (strategy/gs.py:106-115, every iteration until densify.end_iteration = 15000):
+            # per-view position-gradient statistics between backward and optimiser
+            strategy_mod = importlib.import_module("3dgrut_amd.strategy")
+            res_strategy = strategy_mod.GSStrategy(stepper).attach()
     else:
         model = model_mod.GaussianModel(scene, device=dev, sh_degree=sh_degree)
         stepper = train_mod.TrainStep(model, tracer, scene_extent=extent, world_size=world)
@@ -468,6 +473,9 @@ def main():
                          "bring them up to date in registers and do not write them back; gut_hip.h: GutLazyMoments)")
     ap.add_argument("--force-overlap-optimizer", action="store_true",
                     help="always use the side-stream optimiser pass (default: the trainer times both forms in steps 1-4 and keeps the faster)")
+    ap.add_argument("--densification-statistics", action="store_true",
+                    help="native trainer: attach strategy.GSStrategy, whose per-view position-gradient statistics run between backward "
+                         "and optimiser in every step (the densification phase of a reference run; the number is NOT the headline)")
     ap.add_argument("--no-overlap-optimizer", action="store_true",
                     help="one optimiser kernel after the backward instead of the side-stream pass for the waves that cannot receive a gradient")
     args = ap.parse_args()
@@ -601,6 +609,7 @@ def main():
                        "placement_trials_ms": [round(t, 3) for t in getattr(stepper, "placement_trials_ms", [])] or None,
                        "optimizer_overlap": bool(getattr(stepper, "overlap_optimizer", False)),
                        "lazy_moment_decay": bool(getattr(stepper, "lazy_moments", False)),
+                       "densification_statistics": bool(getattr(stepper, "post_backward_hook", None) is not None),
                        "optimizer_overlap_probe_ms": ({k: round(v, 3) for k, v in stepper._overlap_probe.items() if k in ("ms_on", "ms_off")}
                                                       if getattr(stepper, "_overlap_probe", None) else None)},
             "render_ms_per_frame": res["render_ms"],
