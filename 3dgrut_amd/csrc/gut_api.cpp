@@ -134,6 +134,8 @@ struct gut_context {
 
     // per-N scratch
     DevBuf tiles_count, tiles_offset, proj_pos, conic_opacity, extent, depth, feat, grad16, scan_temp;
+    float* stat_accum = nullptr;    // gut_set_position_gradient_statistics: consumed by the next gut_optimize_after_bwd
+    int32_t* stat_denom = nullptr;
     DevBuf packed12;   // gut_trace_fields: the [N,12] rows packed from the caller's four tensors (kept for its backward)
     bool packed_valid = false;
     // per-M scratch
@@ -906,7 +908,10 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
                                      eps, step, d_visibility, d_act12_out, h->early_ran,
                                      (h->early_ran && h->early_args.extra_end) ? h->wave_walked.as<uint8_t>() : nullptr,
                                      h->early_args.block_begin, h->early_ran ? h->early_args.extra_end : 0u, lz,
-                                     (lz.wave_step && h->marks_valid) ? h->wave_walked.as<uint8_t>() : nullptr);
+                                     (lz.wave_step && h->marks_valid) ? h->wave_walked.as<uint8_t>() : nullptr,
+                                     h->stat_accum, h->stat_denom);
+    h->stat_accum = nullptr;   // one optimiser call only (the caller may reallocate its buffers any time)
+    h->stat_denom = nullptr;
     HIP_TRY(hipGetLastError());
     if (timing) {
         (void)hipEventRecord(h->kev[13], s);
@@ -925,6 +930,16 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     return 0;
 }
 
+int gut_set_position_gradient_statistics(gut_handle h, float* d_norm_accum, int32_t* d_norm_denom) {
+    if (!h) return fail("gut_set_position_gradient_statistics: null handle");
+    if ((d_norm_accum == nullptr) != (d_norm_denom == nullptr))
+        return fail("gut_set_position_gradient_statistics: both buffers or neither");
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->stat_accum = d_norm_accum;
+    h->stat_denom = d_norm_denom;
+    return 0;
+}
+
 int gut_optimize_finish_without_gradient(gut_handle h, void* stream_) {
     if (!h) return fail("gut_optimize_finish_without_gradient: null handle");
     std::lock_guard<std::mutex> lock(h->mu);
@@ -934,6 +949,8 @@ int gut_optimize_finish_without_gradient(gut_handle h, void* stream_) {
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
     const gut_context::EarlyArgs ea = h->early_args;
+    h->stat_accum = nullptr;   // (a step finished without its gradient has no statistics either)
+    h->stat_denom = nullptr;
     // discard whatever the backward compositor may have accumulated: every remaining wave sees an exactly-zero gradient
     HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)h->n));
     HIP_TRY(hipMemsetAsync(h->grad16.p, 0, h->grad16.cap, s));

@@ -122,7 +122,8 @@ void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
                                  float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only,
                                  const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end,
-                                 const LazyMoments& lazy, const uint8_t* rule_walked /* per-wave marks valid for EVERY wave, or null */);
+                                 const LazyMoments& lazy, const uint8_t* rule_walked /* per-wave marks valid for EVERY wave, or null */,
+                                 float* stat_accum = nullptr, int32_t* stat_denom = nullptr /* gs.py:106-115 statistics, or null */);
 // Adam step of the rows that get no gradient this iteration (tiles_count == 0), see k_adam_rows_without_gradient
 void launch_compact_gradient_rows(hipStream_t s, uint32_t n, const float* act12, const uint32_t* tiles_count, const float* feat,
                                   float* grad16, float* records, uint32_t capacity, uint32_t* count);

@@ -157,7 +157,34 @@ struct ShAdamParams {
     EarlyOwnership own;            // ... which are these
     int32_t clear_consumed;        // !kScratch: gradient rows that were non-zero are written back as zeros (sparse exchange: the
                                    // dense accumulators are only ever touched where a record landed, never cleared wholesale)
+    float* stat_accum;             // kScratch: the densification statistics of strategy/gs.py:106-115, or null
+    int32_t* stat_denom;           //           (gut_set_position_gradient_statistics)
 };
+
+// strategy/gs.py:106-115 for one Gaussian with a non-zero position gradient of this view:
+//   accum += | grad * |position - sensor| | / 2,   denom += 1
+__device__ __forceinline__ void position_gradient_statistic(float gx, float gy, float gz, float px, float py, float pz,
+                                                            const float* __restrict__ cam, float* accum, int32_t* denom) {
+    const float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float sx = gx * d, sy = gy * d, sz = gz * d;
+    *accum += sqrtf(sx * sx + sy * sy + sz * sz) * 0.5f;
+    *denom += 1;
+}
+
+// the same as a kernel of its own, for the trainer paths whose optimiser kernel does not see the view's own gradient (data
+// parallel exchange, unfused optimiser): grad / pos are rows of `*_stride` floats whose first three columns are used
+__global__ __launch_bounds__(kBlock) void k_position_gradient_statistics(uint32_t n, const float* __restrict__ grad, uint32_t grad_stride,
+                                                                        const float* __restrict__ pos, uint32_t pos_stride,
+                                                                        const float* __restrict__ cam, float* __restrict__ accum,
+                                                                        int32_t* __restrict__ denom) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float gx = grad[(size_t)i * grad_stride + 0], gy = grad[(size_t)i * grad_stride + 1], gz = grad[(size_t)i * grad_stride + 2];
+    if (!(gx != 0.0f || gy != 0.0f || gz != 0.0f)) return;
+    position_gradient_statistic(gx, gy, gz, pos[(size_t)i * pos_stride + 0], pos[(size_t)i * pos_stride + 1],
+                                pos[(size_t)i * pos_stride + 2], cam, accum + i, denom + i);
+}
 
 __device__ __forceinline__ void sh_basis_fast(int deg, float x, float y, float z, float Y[16]) {
 #pragma unroll
@@ -291,6 +318,8 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
                     own_r = feat[3 * (size_t)i + 0] > 0.0f ? g2.w : 0.0f;
                     own_g = feat[3 * (size_t)i + 1] > 0.0f ? g3.x : 0.0f;
                     own_b = feat[3 * (size_t)i + 2] > 0.0f ? g3.y : 0.0f;
+                    if (sp.stat_accum && (g0.x != 0.0f || g0.y != 0.0f || g0.z != 0.0f))
+                        position_gradient_statistic(g0.x, g0.y, g0.z, px, py, pz, sp.cam, sp.stat_accum + i, sp.stat_denom + i);
                     float4 act[3];
                     activate_row(a, b, c, act);
                     g0.w = g0.w * act[0].w * (1.0f - act[0].w);                      // sigmoid
@@ -581,9 +610,10 @@ void launch_sh_adam_from_scratch(hipStream_t s, uint32_t n, int sh_degree, const
                                  float* sh48, float* sh_m, float* sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
                                  float eps, uint32_t step, const float* visibility, float* act12_out, bool rows_with_tiles_only,
                                  const uint8_t* wave_walked, uint32_t split_block, uint32_t extra_end, const LazyMoments& lazy,
-                                 const uint8_t* rule_walked) {
+                                 const uint8_t* rule_walked, float* stat_accum, int32_t* stat_denom) {
     if (n == 0) return;
     ShAdamParams sp;
+    sp.stat_accum = stat_accum; sp.stat_denom = stat_denom;
     sp.lazy = lazy;
     sp.rule_walked = rule_walked;
     sp.rows_with_tiles_only = rows_with_tiles_only ? 1 : 0;
@@ -794,6 +824,18 @@ int gut_selective_adam(void* stream, uint64_t rows, uint32_t cols, float* d_para
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+int gut_position_gradient_statistics(void* stream, uint32_t n, const float* d_position_grad, uint32_t grad_stride, const float* d_positions,
+                                     uint32_t position_stride, const float* d_sensor_position, float* d_norm_accum,
+                                     int32_t* d_norm_denom) {
+    if (n == 0) return 0;
+    if (!d_position_grad || !d_positions || !d_sensor_position || !d_norm_accum || !d_norm_denom) return 1;
+    if (grad_stride < 3 || position_stride < 3) return 3;
+    hipLaunchKernelGGL(gut::k_position_gradient_statistics, dim3((n + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
+                       static_cast<hipStream_t>(stream), n, d_position_grad, grad_stride, d_positions, position_stride,
+                       d_sensor_position, d_norm_accum, d_norm_denom);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int gut_mcmc_relocation(void* stream, int32_t n, const float* d_opacities, const float* d_scales, const int32_t* d_ratios,
                         const float* d_binoms, int32_t n_max, float* d_new_opacities, float* d_new_scales) {
     if (n <= 0) return 0;
@@ -829,6 +871,7 @@ int gut_sh_adam_step_ex(void* stream, uint32_t num_particles, int32_t sh_degree,
     if (lazy && d_visibility) return 3;   // a visibility mask leaves rows untouched: their moments do not decay at all
     sp.lazy = gut_make_lazy(lazy, step);
     sp.rule_walked = nullptr;
+    sp.stat_accum = nullptr; sp.stat_denom = nullptr;
     hipLaunchKernelGGL(gut::k_sh_adam<false>, dim3((num_particles + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
                        static_cast<hipStream_t>(stream), sp, d_mrgb, reinterpret_cast<float4*>(d_raw_grad12),
                        reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_raw_m), reinterpret_cast<float4*>(d_raw_v),

@@ -210,6 +210,11 @@ class NativeTrainStep:
         # differ (dp.assert_replicas_identical): nothing else would notice a diverged replica
         self.replica_check_every = 500
         self.post_backward_hook = None  # callable(position_grad [N,3] of THIS view, sensor_position [3]) — densification stats
+        # callable() -> (norm_accum float32 [N,1], norm_denom int32 [N,1]) GPU tensors or None: the statistics of gs.py:106-115 for
+        # THIS step, accumulated by the fused optimiser kernel itself (gut_set_position_gradient_statistics).  A hook that comes
+        # with it (GSStrategy.attach sets both) no longer takes the step off the fused one- / two-pass optimiser: the hook is only
+        # called on the paths whose optimiser kernel does not see the view's own gradient (data-parallel exchange, unfused).
+        self.fused_statistics = None
         self.row_listeners = []         # callables(perm): told when reorder() re-sorts the rows (strategy statistics follow)
         self.resize_workspace()
         self.phase_timing = False   # record HIP events around the phases of step() (bench / profiling)
@@ -220,7 +225,8 @@ class NativeTrainStep:
         """True while the default-on optimiser overlap is still being timed against the one-pass form (steps PROBE_FIRST ..
         PROBE_LAST of single-view steps with the fused epilogue; data-parallel and hooked steps never probe)."""
         p = self._overlap_probe
-        one_pass = self.fused and self.world_size <= 1 and not self.force_exchange and self.post_backward_hook is None and self.fuse_epilogue
+        one_pass = self.fused and self.world_size <= 1 and not self.force_exchange and self.fuse_epilogue \
+            and (self.post_backward_hook is None or self.fused_statistics is not None)
         return p is not None and not p["done"] and one_pass and not self.selective
 
     def resize_workspace(self):
@@ -464,8 +470,8 @@ class NativeTrainStep:
         m = self.model
         evs = [] if self.phase_timing else None
         self._mark(evs)
-        one_pass = self.fused and self.world_size <= 1 and not self.force_exchange and self.post_backward_hook is None \
-            and self.fuse_epilogue
+        one_pass = self.fused and self.world_size <= 1 and not self.force_exchange and self.fuse_epilogue \
+            and (self.post_backward_hook is None or self.fused_statistics is not None)
         use_overlap, probe_evs = self.overlap_optimizer, None
         probe = self._overlap_probe
         if probe is not None and one_pass and not self.selective:
@@ -534,6 +540,9 @@ class NativeTrainStep:
                 self.raster.trace_bwd(*bwd_args, skip_epilogue=True)
                 self._mark(evs)
                 vmask = vis.reshape(-1) if self.selective else None
+                stats = self.fused_statistics() if self.fused_statistics is not None else None
+                if stats is not None:
+                    self.raster.set_position_gradient_statistics(*stats)
                 self.raster.optimize_after_bwd(m.n_active_features, self._sensor_position(batch), m.raw, self.m12, self.v12, m.features,
                                                self.m48, self.v48, self.lr12, self.lr48, self.betas, self.eps,
                                                0 if self.selective else self.step_id + 1, vmask, self.act, lazy=self._lazy())

@@ -120,6 +120,8 @@ class GSStrategy:
     def attach(self):
         s = self.ops.s
         s.post_backward_hook = self._post_backward
+        if hasattr(s, "fused_statistics"):
+            s.fused_statistics = self._fused_statistics   # one view, fused optimiser: the optimiser kernel accumulates them itself
         listeners = getattr(s, "row_listeners", None)
         if listeners is not None and self._rows_reordered not in listeners:
             listeners.append(self._rows_reordered)
@@ -129,6 +131,18 @@ class GSStrategy:
         s = self.ops.s
         if getattr(s, "post_backward_hook", None) == self._post_backward:
             s.post_backward_hook = None
+        if getattr(s, "fused_statistics", None) == self._fused_statistics:
+            s.fused_statistics = None
+
+    def _fused_statistics(self):
+        """The buffers the trainer's fused optimiser kernel accumulates this step's statistics into, or None when this step has none
+        (same schedule as _post_backward)."""
+        from .schedule import check_step_condition
+        if not check_step_condition(int(getattr(self.ops.s, "step_id", 1)), 0, self.schedule["densify"][1], 1):
+            return None
+        if not self.grad_norm_accum.is_cuda or self.grad_norm_accum.shape[0] != self.ops.n:
+            raise RuntimeError("[3dgut] densification buffers and the model differ in their number of rows")
+        return self.grad_norm_accum, self.grad_norm_denom
 
     def _post_backward(self, position_grad, sensor_position):
         """gs.py:60-66: the buffer is updated for 0 < step < densify.end_iteration."""
@@ -168,6 +182,18 @@ class GSStrategy:
     @torch.no_grad()
     def update_gradient_buffer(self, position_grad, sensor_position):
         """gs.py:106-115; position_grad = this view's dL/dpositions [N,3] (before any cross-rank exchange)."""
+        if position_grad.is_cuda and position_grad.dtype == torch.float32 and position_grad.stride(1) == 1:
+            # one kernel (gut_position_gradient_statistics) instead of ten torch launches and a boolean-index synchronisation
+            raw = self.ops.m.raw
+            cam = sensor_position.to(device=raw.device, dtype=torch.float32).reshape(-1)[:3].contiguous()
+            st = torch.cuda.current_stream(raw.device).cuda_stream
+            with torch.cuda.device(raw.device):
+                rc = _capi.load().gut_position_gradient_statistics(C.c_void_p(st), raw.shape[0], position_grad.data_ptr(), position_grad.stride(0),
+                                                                   raw.data_ptr(), raw.stride(0), cam.data_ptr(),
+                                                                   self.grad_norm_accum.data_ptr(), self.grad_norm_denom.data_ptr())
+            if rc:
+                raise RuntimeError(f"[3dgut] position_gradient_statistics failed ({rc})")
+            return
         mask = (position_grad != 0).any(dim=1)
         dist = (self.ops.m.raw[:, POS][mask] - sensor_position).norm(dim=1, keepdim=True)
         self.grad_norm_accum[mask] += torch.norm(position_grad[mask] * dist, dim=-1, keepdim=True) / 2

@@ -393,6 +393,20 @@ class SplatRaster:
         _capi.check(rc, "trace_bwd_model_fields")
         return pos_g, dns_g, rot_g, scl_g, alb_g, spec_g
 
+    def set_position_gradient_statistics(self, norm_accum, norm_denom):
+        """The NEXT optimize_after_bwd also accumulates GSStrategy.update_gradient_buffer's statistics (gs.py:106-115) into these two
+        [N,1] tensors (float32 / int32), from the gradient rows and pre-update positions it holds anyway."""
+        if norm_accum is None:
+            _capi.check(self._lib.gut_set_position_gradient_statistics(self._handle, None, None), "set_position_gradient_statistics")
+            return
+        if not (norm_accum.is_cuda and norm_accum.dtype == torch.float32 and norm_accum.is_contiguous()
+                and norm_denom.is_cuda and norm_denom.dtype == torch.int32 and norm_denom.is_contiguous()
+                and norm_accum.numel() == norm_denom.numel()):
+            raise RuntimeError("[3dgut] statistics buffers: contiguous GPU tensors, float32 accum and int32 denom of equal length")
+        self._stat_rows = int(norm_accum.numel())   # (checked against N by the caller: the handle's N is the forward's)
+        _capi.check(self._lib.gut_set_position_gradient_statistics(self._handle, norm_accum.data_ptr(), norm_denom.data_ptr()),
+                    "set_position_gradient_statistics")
+
     def optimize_after_bwd(self, num_active_features, camera_position, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps,
                            step, visibility=None, act_out=None, lazy=None):
         """Per-Gaussian backward epilogue + SH-gradient rebuild + Adam in one pass (gut_optimize_after_bwd); follows a

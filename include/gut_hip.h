@@ -31,7 +31,7 @@ extern "C" {
 /* Bumped on every change of a struct layout, an array length or an entry point's signature (2: GutStats grew to 80 bytes and
  * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: GutLazyMoments in the gut_optimize_* / gut_sh_adam_step_ex signatures, gut_sync_moments,
  * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev, gut_trace_fields / gut_trace_bwd_fields;
- * 4: gut_trace_model_fields / gut_trace_bwd_model_fields). */
+ * 4: gut_trace_model_fields / gut_trace_bwd_model_fields, gut_position_gradient_statistics, gut_set_position_gradient_statistics). */
 #define GUT_ABI_VERSION 4
 
 typedef struct gut_context* gut_handle;
@@ -429,6 +429,20 @@ int gut_adam_unwalked_waves(void* stream, uint32_t num_particles, const uint8_t*
 int gut_adam_unwalked_waves_ex(void* stream, uint32_t num_particles, const uint8_t* d_wave_flags, float* d_raw12, float* d_raw_m,
                                float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48,
                                float beta1, float beta2, float eps, uint32_t step, float* d_act12_out, const GutLazyMoments* lazy);
+
+/* ---- "next" row N3: the densification statistics of GSStrategy.update_gradient_buffer (threedgrut/strategy/gs.py:
+ * 106-115), which the reference's trainer runs between backward and optimiser in every iteration up to densify.end_iteration
+ * (trainer.py:741-743): for every Gaussian whose position gradient of THIS view is non-zero,
+ *     norm_accum[i] += | grad_i * |position_i - sensor_position| | / 2,      norm_denom[i] += 1.
+ * gut_position_gradient_statistics is that as one kernel (grad / positions: rows of `*_stride` floats, first three columns used;
+ * d_sensor_position: device float[3]).  gut_set_position_gradient_statistics folds it into the NEXT gut_optimize_after_bwd on the
+ * handle (that kernel holds each row's gradient and pre-update position in registers anyway; the setting is consumed by that one
+ * call, so the caller may reallocate its buffers between steps; NULL, NULL clears it): the step keeps its fused one- or two-pass
+ * optimiser instead of materialising the [N,3] gradient for a hook (6.5 -> 2.6 ms per step at 6 M Gaussians). */
+int gut_position_gradient_statistics(void* stream, uint32_t num_particles, const float* d_position_grad, uint32_t grad_stride,
+                                     const float* d_positions, uint32_t position_stride, const float* d_sensor_position,
+                                     float* d_norm_accum, int32_t* d_norm_denom);
+int gut_set_position_gradient_statistics(gut_handle h, float* d_norm_accum, int32_t* d_norm_denom);
 
 /* ---- "next" row N3: MCMC relocation kernel (threedgrut/strategy/src/gaussian_mcmc.cu:33-73).
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */
