@@ -445,6 +445,12 @@ class NativeTrainStep:
         # whole steps, event to event (GPU time incl. any wait for the host): the slowest one shows a one-off stall
         spans = sorted(evs[0].elapsed_time(evs[len(names)]) for evs in self._phase_events)
         self.last_step_spans_ms = dict(min=spans[0], median=spans[len(spans) // 2], max=spans[-1])
+        if os.environ.get("GUT_STEP_SPANS") == "1":
+            self.last_step_spans_ms["all"] = [[round(evs[k].elapsed_time(evs[k + 1]), 3) for k in range(len(names))] for evs in self._phase_events]
+        if spans[-1] > 3.0 * spans[len(spans) // 2]:   # a one-off stall: say where (step index within the timed region, phase)
+            worst = max(range(n), key=lambda i: self._phase_events[i][0].elapsed_time(self._phase_events[i][len(names)]))
+            evs = self._phase_events[worst]
+            self.last_step_spans_ms["slowest"] = dict(index=worst, **{names[k]: evs[k].elapsed_time(evs[k + 1]) for k in range(len(names))})
         if reset:
             self._phase_events = []
         return {names[k]: acc[k] / n for k in range(len(names))}

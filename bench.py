@@ -19,6 +19,7 @@ plus "render_ms_per_frame" (forward-only, event time around the whole forward in
 the reference's `forward_render` definition) and the scene statistics N,V,M,T,P,E_f,E_b.
 """
 import argparse
+import gc
 import importlib
 import json
 import math
@@ -361,6 +362,9 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     raster.collect_times()
     if hasattr(stepper, "phase_timing"):
         stepper.phase_timing = True
+    # start from a collected heap: a full (generation-2) collection of the Python heap is a 40 - 60 ms host pause in this process
+    # (seen at a fixed step of the run: 2.6 -> 4.3 ms/step over 30 steps); real training pays it once in thousands of steps
+    gc.collect()
     t0 = time.perf_counter()
     for s in range(steps):
         stepper.step(batch_for(warmup + s))
@@ -407,6 +411,7 @@ def run_drop_in(res, steps=8, warmup=3, optimizer_type="adam"):
         stepper.step(res["batch_for"](s))
     torch.cuda.synchronize(dev)
     res["tracer"].tracer_wrapper.collect_times()
+    gc.collect()
     t0 = time.perf_counter()
     for s in range(steps):
         stepper.step(res["batch_for"](warmup + s))

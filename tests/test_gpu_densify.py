@@ -236,19 +236,24 @@ def test_statistics_fused_into_the_optimiser_equal_the_hook():
         gs.update_gradient_buffer = lambda pg, sp: (calls.append(1), inner(pg, sp))[1]
         for k in range(5):
             st.step(_batch(views[k % 4], gt))
+            if k == 1:   # the first step with statistics (step 0 has none, gs.py:64): the two trainers still hold the same parameters
+                first = (gs.grad_norm_accum.clone(), gs.grad_norm_denom.clone())
         st.sync_moments()
-        assert len(calls) == (0 if fused else 5)           # fused: the hook is never called
+        assert len(calls) == (0 if fused else 4)           # fused: the hook is never called (unfused: every step but step 0)
         assert st.overlap_optimizer is True
-        runs[fused] = (gs.grad_norm_accum.clone(), gs.grad_norm_denom.clone(), model.raw.clone(), st.raster.stats())
-    (a1, d1, r1, s1), (a0, d0, r0, s0) = runs[True], runs[False]
+        runs[fused] = (first, gs.grad_norm_accum.clone(), gs.grad_norm_denom.clone(), model.raw.clone(), st.raster.stats())
+    (f1, a1, d1, r1, s1), (f0, a0, d0, r0, s0) = runs[True], runs[False]
     assert s1["side_stream_rows"] > 0 and s0["side_stream_rows"] == 0   # only the fused form keeps the side-stream pass
-    assert int(d0.sum()) > 10_000 and int(d0.max()) >= 2
-    # rows whose gradient of a view is a sum of float atomics that cancels to exactly zero in one order and not in the other are
-    # counted differently: not seen, allowed for a handful
-    assert int((d1 != d0).sum()) <= 3
-    same = (d1 == d0).squeeze(1)
-    assert torch.allclose(a1[same], a0[same], rtol=2e-4, atol=1e-9)
-    assert torch.allclose(r1, r0, rtol=1e-3, atol=1e-5)
+    # one view's statistics from (up to the atomics of step 0's update) the same parameters: the same rows counted — but for a
+    # handful whose gradient is a sum of float atomics that cancels to exactly zero in one order only — and the same norms
+    assert int(f0[1].sum()) > 5_000 and int((f1[1] != f0[1]).sum()) <= 3
+    same = (f1[1] == f0[1]).squeeze(1)
+    rel = ((f1[0] - f0[0]).abs() / f0[0].abs().clamp_min(1e-3 * float(f0[0].max())))[same]
+    assert float(rel.max()) <= 2e-3 and float(torch.quantile(rel[:1_000_000], 0.999)) <= 2e-4, (float(rel.max()),)
+    # four views later the two runs have drifted apart by their atomics' orders; the statistics still agree as a whole
+    assert int(d0.max()) >= 2 and int((d1 != d0).sum()) <= 5e-3 * d0.numel()
+    assert float((a1 - a0).norm() / a0.norm()) <= 2e-2
+    assert torch.allclose(r1, r0, rtol=1e-2, atol=1e-4)
     # detach at densify.end_iteration: both entries go
     gs.detach()
     assert st.post_backward_hook is None and st.fused_statistics is None
