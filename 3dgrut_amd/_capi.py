@@ -75,7 +75,7 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation",
            "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev", "gut_adam_unwalked_waves_ex", "gut_sync_moments", "gut_trace_fields", "gut_trace_bwd_fields", "gut_selective_adam",
            "gut_trace_model_fields", "gut_trace_bwd_model_fields", "gut_position_gradient_statistics",
-           "gut_set_position_gradient_statistics")
+           "gut_set_position_gradient_statistics", "gut_mcmc_perturb")
 
 _lib = None
 
@@ -110,6 +110,7 @@ def load():
                                                f_p, f_p, f_p, f_p, f_p, f_p]
     lib.gut_position_gradient_statistics.argtypes = [vp, u32, f_p, u32, f_p, u32, f_p, f_p, vp]
     lib.gut_set_position_gradient_statistics.argtypes = [vp, f_p, vp]
+    lib.gut_mcmc_perturb.argtypes = [vp, u32, f_p, f_p, C.c_float, C.c_uint64, C.c_uint64, f_p]
     lib.gut_collect_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.gut_get_stats.argtypes = [vp, C.POINTER(GutStats)]
     lib.gut_debug_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]

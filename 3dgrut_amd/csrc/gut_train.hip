@@ -104,6 +104,68 @@ __global__ __launch_bounds__(kBlock) void k_mcmc_relocation(int n, const float* 
     for (int c = 0; c < 3; ++c) new_scales[idx * 3 + c] = coeff * scales[idx * 3 + c];
 }
 
+// k_mcmc_perturb: MCMCStrategy.perturb_gaussians (threedgrut/strategy/mcmc.py:147-164) as one pass over the raw rows:
+//   positions += Sigma @ (unit_normal * op_sigmoid(1 - density) * noise_lr * position_lr),  Sigma = R S S^T R^T (model.py:95-105),
+//   op_sigmoid(x) = 1 / (1 + exp(-100 (x - 0.995))).
+// (the reference builds [N,3,3] covariances with four batched 3x3 matmuls for it: 250 ms at 6 M Gaussians on this chip.)
+// unit == nullptr: three standard-normal draws per Gaussian from Philox4x32-10 keyed by (seed, step), counter = the row index
+// (Box-Muller on its four words) — the same draws on every data-parallel rank, whatever the launch geometry.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mcmc_perturb(uint32_t n, float4* __restrict__ raw, float4* __restrict__ act, float noise_scale,
+                                                        uint32_t key0, uint32_t key1, uint32_t ctr_hi, const float* __restrict__ unit) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 a = raw[3 * (size_t)i + 0];
+    const float4 q = raw[3 * (size_t)i + 1], ls = raw[3 * (size_t)i + 2];
+    float u0, u1, u2;
+    if (unit) {
+        u0 = unit[3 * (size_t)i + 0]; u1 = unit[3 * (size_t)i + 1]; u2 = unit[3 * (size_t)i + 2];
+    } else {
+        uint32_t w[4];
+        philox4x32_10(i, ctr_hi, 0u, 0u, key0, key1, w);
+        // Box-Muller: (0,1] uniforms from the top 24 bits, two independent pairs
+        const float f0 = ((float)(w[0] >> 8) + 1.0f) * 0x1p-24f, f1 = (float)(w[1] >> 8) * 0x1p-24f;
+        const float f2 = ((float)(w[2] >> 8) + 1.0f) * 0x1p-24f, f3 = (float)(w[3] >> 8) * 0x1p-24f;
+        const float r0 = sqrtf(-2.0f * logf(f0)), r1 = sqrtf(-2.0f * logf(f2));
+        u0 = r0 * cosf(6.283185307179586f * f1);
+        u1 = r0 * sinf(6.283185307179586f * f1);
+        u2 = r1 * cosf(6.283185307179586f * f3);
+    }
+    const float dens = 1.0f / (1.0f + expf(-a.w));
+    const float gate = 1.0f / (1.0f + expf(-100.0f * ((1.0f - dens) - 0.995f)));
+    const float g = gate * noise_scale;
+    const float n0 = u0 * g, n1 = u1 * g, n2 = u2 * g;
+    // R from the normalised quaternion (wxyz; utils/misc.py:69-90), Sigma n = R S^2 R^T n
+    const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float r = q.x / nrm, x = q.y / nrm, y = q.z / nrm, z = q.w / nrm;
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    const float s0 = expf(ls.x), s1 = expf(ls.y), s2 = expf(ls.z);
+    const float t0 = (R[0][0] * n0 + R[1][0] * n1 + R[2][0] * n2) * s0 * s0;   // S^2 R^T n
+    const float t1 = (R[0][1] * n0 + R[1][1] * n1 + R[2][1] * n2) * s1 * s1;
+    const float t2 = (R[0][2] * n0 + R[1][2] * n1 + R[2][2] * n2) * s2 * s2;
+    a.x += R[0][0] * t0 + R[0][1] * t1 + R[0][2] * t2;
+    a.y += R[1][0] * t0 + R[1][1] * t1 + R[1][2] * t2;
+    a.z += R[2][0] * t0 + R[2][1] * t1 + R[2][2] * t2;
+    raw[3 * (size_t)i + 0] = a;
+    if (act) {   // the activated row of the next forward: positions are not activated, the rest is unchanged
+        float4 b = act[3 * (size_t)i + 0];
+        b.x = a.x; b.y = a.y; b.z = a.z;
+        act[3 * (size_t)i + 0] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // k_sh_adam: fused (multi-view) SH-gradient rebuild + Adam for both parameter tensors, one wave per 64 Gaussians.
 // The [N,48] SH gradient never exists in memory: each lane rebuilds its Gaussian's 48 gradient values from the
@@ -833,6 +895,17 @@ int gut_position_gradient_statistics(void* stream, uint32_t n, const float* d_po
     hipLaunchKernelGGL(gut::k_position_gradient_statistics, dim3((n + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0,
                        static_cast<hipStream_t>(stream), n, d_position_grad, grad_stride, d_positions, position_stride,
                        d_sensor_position, d_norm_accum, d_norm_denom);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int gut_mcmc_perturb(void* stream, uint32_t n, float* d_raw12, float* d_act12, float noise_scale, uint64_t seed, uint64_t step,
+                     const float* d_unit_normals) {
+    if (n == 0) return 0;
+    if (!d_raw12) return 1;
+    if (!(noise_scale == noise_scale)) return 3;
+    hipLaunchKernelGGL(gut::k_mcmc_perturb, dim3((n + gut::kBlock - 1) / gut::kBlock), dim3(gut::kBlock), 0, static_cast<hipStream_t>(stream),
+                       n, reinterpret_cast<float4*>(d_raw12), reinterpret_cast<float4*>(d_act12), noise_scale, (uint32_t)seed,
+                       (uint32_t)(seed >> 32) ^ (uint32_t)step, (uint32_t)(step >> 32), d_unit_normals);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -365,6 +365,22 @@ class MCMCStrategy:
     @torch.no_grad()
     def perturb(self, position_lr, step=0):
         m = self.ops.m
+        if m.raw.is_cuda:
+            # one kernel over the raw rows (gut_mcmc_perturb): the reference's [N,3,3] covariance matmuls take 250 ms at 6 M Gaussians
+            unit = None
+            if self.unit_normal_fn is not None:
+                unit = self.unit_normal_fn(m.raw[:, POS].shape, step).to(device=m.raw.device, dtype=torch.float32).contiguous()
+            act = getattr(self.ops.s, "act", None)
+            if act is not None and (act.shape[0] != m.raw.shape[0] or not act.is_cuda):
+                act = None
+            st = torch.cuda.current_stream(m.raw.device).cuda_stream
+            with torch.cuda.device(m.raw.device):
+                rc = _capi.load().gut_mcmc_perturb(C.c_void_p(st), m.raw.shape[0], m.raw.data_ptr(), None if act is None else act.data_ptr(),
+                                                   float(self.noise_lr * position_lr), int(self.seed), int(step),
+                                                   None if unit is None else unit.data_ptr())
+            if rc:
+                raise RuntimeError(f"[3dgut] mcmc_perturb failed ({rc})")
+            return
         R = _quat_to_rotmat(m.raw[:, ROT])
         S = torch.diag_embed(torch.exp(m.raw[:, SCL].contiguous()))
         cov = R @ S @ S.transpose(1, 2) @ R.transpose(1, 2)

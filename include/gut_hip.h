@@ -31,7 +31,8 @@ extern "C" {
 /* Bumped on every change of a struct layout, an array length or an entry point's signature (2: GutStats grew to 80 bytes and
  * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: GutLazyMoments in the gut_optimize_* / gut_sh_adam_step_ex signatures, gut_sync_moments,
  * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev, gut_trace_fields / gut_trace_bwd_fields;
- * 4: gut_trace_model_fields / gut_trace_bwd_model_fields, gut_position_gradient_statistics, gut_set_position_gradient_statistics). */
+ * 4: gut_trace_model_fields / gut_trace_bwd_model_fields, gut_position_gradient_statistics, gut_set_position_gradient_statistics,
+ * gut_mcmc_perturb). */
 #define GUT_ABI_VERSION 4
 
 typedef struct gut_context* gut_handle;
@@ -448,6 +449,15 @@ int gut_set_position_gradient_statistics(gut_handle h, float* d_norm_accum, int3
  * opacities [n], scales [n,3], ratios [n] (int32, 1..n_max), binoms [n_max,n_max] -> new_opacities [n], new_scales [n,3] */
 int gut_mcmc_relocation(void* stream, int32_t n, const float* d_opacities, const float* d_scales, const int32_t* d_ratios,
                         const float* d_binoms, int32_t n_max, float* d_new_opacities, float* d_new_scales);
+
+/* MCMCStrategy.perturb_gaussians (threedgrut/strategy/mcmc.py:147-164), which the reference's trainer runs after EVERY optimiser
+ * step of an MCMC run (configs/strategy/mcmc.yaml: perturb.frequency 1): positions += Sigma @ (unit_normal * op_sigmoid(1 - density) *
+ * noise_scale) on the raw [N,12] rows (pos3 | density logit | quat wxyz raw | log-scale3 | pad), Sigma = R S S^T R^T, noise_scale =
+ * perturb.noise_lr * the current position learning rate.  d_act12 (may be NULL): the trainer's activated rows, whose positions are
+ * updated too.  d_unit_normals (may be NULL): [N,3] standard-normal draws to use; NULL = Philox4x32-10 keyed by (seed, step) with the
+ * row index as counter (the same draws on every rank).  One pass, 96 bytes per Gaussian, instead of four batched 3x3 matmuls. */
+int gut_mcmc_perturb(void* stream, uint32_t num_particles, float* d_raw12, float* d_act12, float noise_scale, uint64_t seed,
+                     uint64_t step, const float* d_unit_normals);
 
 const char* gut_last_error(void);
 int gut_abi_version(void);

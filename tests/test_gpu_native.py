@@ -196,6 +196,57 @@ def test_mcmc_relocation_kernel_on_what_the_reference_hands_it():
     assert max(int(S[f"kernel{i}/ratios"].max()) for i in range(3)) >= 3
 
 
+def test_mcmc_perturb_kernel():
+    """gut_mcmc_perturb against MCMCStrategy.perturb_gaussians restated with torch (mcmc.py:147-164, model.py:95-105, misc.py:69-90)
+    for given standard-normal draws; its own draws (Philox4x32-10 keyed by seed and step, counter = row) are standard normal,
+    reproducible, different from step to step, and the trainer's activated rows follow the positions."""
+    strategy = importlib.import_module("3dgrut_amd.strategy")
+    n = 200_000
+    sc = scenes.scene_c1(n, 4)
+    sc["density"] = np.random.default_rng(0).uniform(1e-4, 0.02, size=(n, 1)).astype(np.float32)   # around the gate's knee (0.005)
+    mn = native.NativeGaussianModel(sc, device=DEV)
+    st = native.NativeTrainStep(mn, gut.Tracer({"render": {}}), scene_extent=1.0)
+    st.activate()
+    mc = strategy.MCMCStrategy(st, noise_lr=5e5, seed=3)
+    raw0 = mn.raw.clone()
+    unit = torch.randn((n, 3), generator=torch.Generator().manual_seed(1)).to(DEV)
+    mc.unit_normal_fn = lambda shape, step: unit
+    lr = 1.6e-4
+    mc.perturb(lr, step=5)
+    # the reference's lines, float64
+    q = torch.nn.functional.normalize(raw0[:, 4:8].double(), dim=1)
+    r, x, y, z = q.unbind(1)
+    R = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)], 1),
+                     torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)], 1),
+                     torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1)], 1)
+    S = torch.diag_embed(torch.exp(raw0[:, 8:11].double()))
+    cov = R @ S @ S.transpose(1, 2) @ R.transpose(1, 2)
+    dens = torch.sigmoid(raw0[:, 3:4].double())
+    noise = unit.double() * (1 / (1 + torch.exp(-100 * ((1 - dens) - 0.995)))) * 5e5 * lr
+    want = torch.bmm(cov, noise.unsqueeze(-1)).squeeze(-1)
+    got = (mn.raw[:, 0:3] - raw0[:, 0:3]).double()
+    assert float(want.abs().max()) > 1e-4
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 2e-7        # (fp32 position ulp at |p| ~ 1: 6e-8)
+    assert torch.equal(mn.raw[:, 3:], raw0[:, 3:])                                           # nothing but the positions moves
+    assert torch.equal(st.act[:, 0:3], mn.raw[:, 0:3]) and torch.equal(st.activate()[:, 0:3], mn.raw[:, 0:3])
+    # the kernel's own draws: identity rotations, unit scales, transparent Gaussians (gate ~ 1) -> displacement = draw * scale
+    mn.raw.zero_(); mn.raw[:, 4] = 1.0; mn.raw[:, 3] = -30.0
+    mc.unit_normal_fn = None
+    draws = []
+    for step in (7, 7, 8):
+        mn.raw[:, 0:3] = 0.0
+        mc.perturb(2e-6, step=step)                 # noise_lr * lr = 1
+        draws.append(mn.raw[:, 0:3].clone())
+    assert torch.equal(draws[0], draws[1]) and not torch.equal(draws[0], draws[2])
+    gate = 1 / (1 + math.exp(-100 * ((1 - 1 / (1 + math.exp(30.0))) - 0.995)))
+    u = draws[0].double() / gate
+    assert abs(float(u.mean())) < 5e-3 and abs(float(u.var()) - 1.0) < 1e-2
+    assert abs(float((u ** 4).mean()) - 3.0) < 0.1 and float(u.abs().max()) < 6.5                 # kurtosis of a normal; 600 k draws
+    c = torch.corrcoef(torch.cat([u, draws[2].double() / gate], 1).T)
+    assert float((c - torch.eye(6, dtype=c.dtype, device=c.device)).abs().max()) < 1e-2       # components and steps uncorrelated
+    assert float((u[1:, 0] * u[:-1, 0]).mean().abs()) < 1e-2                                  # neighbouring rows too
+
+
 def test_mcmc_strategy_on_the_live_trainer():
     """post_optimizer_step (mcmc.py:76-90) between native train steps, with the lazily decayed moments on: at an iteration the
     schedule selects for all three operations the dead Gaussians are relocated, 5 % are added (new rows: zero moments) and the
