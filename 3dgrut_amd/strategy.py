@@ -70,10 +70,11 @@ class _StateOps:
         s.resize_workspace()
 
     def keep(self, mask):
-        self._apply(lambda p: p[mask].contiguous(), lambda v: v[mask].contiguous())
+        idx = mask.nonzero().squeeze(1)   # once, not once per tensor (p[mask] finds the indices — and synchronises — every time)
+        self._apply(lambda p: p.index_select(0, idx), lambda v: v.index_select(0, idx))
         perm = getattr(self.m, "permutation", None)
         if perm is not None:   # stored row i came from row permutation[i] of the scene as given; rows added later get -1
-            self.m.permutation = perm[mask.to(perm.device)]
+            self.m.permutation = perm.index_select(0, idx.to(perm.device))
 
     def append(self, raw_new, feat_new):
         s, m = self.s, self.m
@@ -157,10 +158,10 @@ class GSStrategy:
     def post_optimizer_step(self, step, scene_extent, world=1):
         """gs.py:75-104 with utils/misc.check_step_condition.  Returns True when the number or order of rows changed."""
         from .schedule import check_step_condition
-        sc, updated = self.schedule, False
+        sc, updated, appended = self.schedule, False, False
         if check_step_condition(step, *sc["densify"]):
             self.densify(scene_extent, step, world)
-            updated = True
+            updated = appended = True
         if check_step_condition(step, *sc["prune"]):
             self.prune_opacity()
             updated = True
@@ -170,8 +171,8 @@ class GSStrategy:
             self.reset_density()
         if step >= sc["densify"][1]:
             self.detach()   # update_gradient_buffer only runs up to densify.end_iteration (gs.py:64)
-        if updated and getattr(self.ops.m, "spatial_order", False):
-            self.ops.s.restore_spatial_order()
+        if appended and getattr(self.ops.m, "spatial_order", False):
+            self.ops.s.restore_spatial_order()   # (pruning alone keeps the rows in their order along the curve)
         return updated
 
     def reset_buffers(self):
