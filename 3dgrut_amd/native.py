@@ -304,7 +304,7 @@ class NativeTrainStep:
             fn(perm)
         self.resize_workspace()
 
-    def tune_placement(self, attempts=2):
+    def tune_placement(self, attempts=4):
         """Re-place the three [N,48] state tensors (SH parameters and their two moments) in HBM where that makes the optimiser's
         stream faster; call once after the model is built and again after densification / reorder, which re-allocate.
 
@@ -314,9 +314,11 @@ class NativeTrainStep:
         way, virtual offsets inside one allocation do not matter, and ONE arena holding all seven (contiguous or interleaved by
         64-row blocks) always lands on the slow plateau.  So: time a no-op pass of the side-stream kernel over every row (zero
         learning rates, beta = 1: every value is rewritten with itself), then give each big tensor up to `attempts` fresh
-        allocations, keeping a move only if the pass gets > 3 % faster.  Values are untouched; transient memory is at most
-        3 x attempts copies of ONE [N,48] tensor (6.9 GB at 6 M Gaussians; the first version of this held eight copies of the
-        whole state).  Returns the pass times in ms, first = where the state was."""
+        allocations, round robin, until one move makes the pass > 3 % faster (the rates are bimodal: 1.76 - 1.78 against 1.50 -
+        1.54 ms at 6 M Gaussians, so the first faster trial is the fast plateau and the search ends; with two attempts per tensor
+        four processes in a row stayed on the slow plateau, with four the odds of that are small).  Values are untouched; transient
+        memory is at most 3 x attempts copies of ONE [N,48] tensor (13.8 GB at 6 M Gaussians; the first version of this held
+        eight copies of the whole state).  Returns the pass times in ms, first = where the state was."""
         m = self.model
         n = m.num_gaussians
         if n == 0 or not m.raw.is_cuda:
@@ -348,11 +350,13 @@ class NativeTrainStep:
         times = [timed()]
         best = times[0]
         held = []         # rejected / replaced allocations stay alive until the end, so that a "fresh" allocation IS fresh
-        for obj, name in ((m, "features"), (self, "m48"), (self, "v48")):
-            for _ in range(max(0, int(attempts))):
+        found = False
+        for _ in range(max(0, int(attempts))):       # round robin over the three tensors; the rates are bimodal, so the first
+            for obj, name in ((m, "features"), (self, "m48"), (self, "v48")):   # trial that is > 3 % faster ends the search
                 free_bytes, _ = torch.cuda.mem_get_info(dev)
                 old = getattr(obj, name)
                 if free_bytes < 2 * old.numel() * old.element_size():
+                    found = True   # (no room for another copy: stop)
                     break
                 setattr(obj, name, old.clone())
                 t = timed()
@@ -360,9 +364,12 @@ class NativeTrainStep:
                 if t < 0.97 * best:
                     best = t
                     held.append(old)
+                    found = True
                     break
                 held.append(getattr(obj, name))
                 setattr(obj, name, old)
+            if found:
+                break
         del held
         self._act_key = None
         torch.cuda.empty_cache()

@@ -304,7 +304,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
             # total, so the scene statistics stay what they are.
             synthetic_optimizer_state(stepper)
         if model.num_gaussians >= 1_000_000 and not getattr(args, "no_placement_tuning", False):
-            stepper.tune_placement()   # re-places the three [N,48] state tensors where that makes the optimiser's stream faster
+            stepper.tune_placement(attempts=getattr(args, "placement_attempts", 4))   # re-places the three [N,48] state tensors where that makes the optimiser's stream faster
         if getattr(args, "densification_statistics", False):
             # the first half of a reference run (strategy/gs.py:106-115, every iteration until densify.end_iteration = 15000):
             # per-view position-gradient statistics between backward and optimiser
@@ -464,6 +464,7 @@ def main():
     ap.add_argument("--no-placement-tuning", action="store_true",
                     help="keep the trainer state where the allocator first put it (default: NativeTrainStep.tune_placement re-places the three "
                          "[N,48] tensors, each at most twice, while the optimiser's no-op pass gets > 3 %% faster)")
+    ap.add_argument("--placement-attempts", type=int, default=4, help="fresh allocations tried per [N,48] tensor by tune_placement (it stops at the first that is faster)")
     ap.add_argument("--ply", default=None,
                     help="render / train THIS scene instead of the synthetic stand-in: a 3DGS-compatible PLY (threedgrut/model/model.py:"
                          "671-719 layout, 3dgrut_amd/io_ply.py); cameras are the named workload's orbit unless --colmap is given")

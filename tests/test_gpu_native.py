@@ -544,11 +544,13 @@ def test_placement_tuning_moves_the_state_without_changing_it():
     ptrs = {k: v.data_ptr() for k, v in state(tuned).items()}
     act_before = tuned.activate().clone()
     times = tuned.tune_placement(attempts=2)
-    assert 4 <= len(times) <= 7 and all(t > 0 for t in times) and tuned.placement_trials_ms == times   # the start + <= 2 per big tensor
+    # the start + at most 2 per big tensor; the first trial that is > 3 % faster ends the search
+    assert 2 <= len(times) <= 7 and all(t > 0 for t in times) and tuned.placement_trials_ms == times
+    assert all(t >= 0.97 * times[0] for t in times[1:-1])
     for k, v in state(tuned).items():
         assert torch.equal(v, before[k]), k
     moved = [k for k in ptrs if state(tuned)[k].data_ptr() != ptrs[k]]
-    assert set(moved) <= {"features", "m48", "v48"}                     # only the three [N,48] tensors are ever re-placed ...
+    assert set(moved) <= {"features", "m48", "v48"} and len(moved) <= 1   # only one of the three [N,48] tensors is ever re-placed ...
     assert bool(moved) == (min(times[1:]) < 0.97 * times[0])            # ... and only for a pass that got > 3 % faster
     assert torch.equal(tuned.activate(), act_before)
     for st in steppers:

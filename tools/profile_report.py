@@ -5,7 +5,7 @@ import csv, glob, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "round2"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "round3"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 # (regex on the demangled kernel name, bench key).  Templated names: k_render<true>(, k_render_backward<false>(, k_sh_adam<true>(
