@@ -303,8 +303,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
             # by any of the eight views).  |m| / sqrt(v) = 0.01: the parameters drift by less than 0.1 learning-rate steps in
             # total, so the scene statistics stay what they are.
             synthetic_optimizer_state(stepper)
-        if model.num_gaussians >= 1_000_000 and not getattr(args, "no_placement_tuning", False):
-            stepper.tune_placement(attempts=getattr(args, "placement_attempts", 4))   # re-places the three [N,48] state tensors where that makes the optimiser's stream faster
+        # (NativeTrainStep.tune_placement runs after the first two warm-up steps, below)
         if getattr(args, "densification_statistics", False):
             # the first half of a reference run (strategy/gs.py:106-115, every iteration until densify.end_iteration = 15000):
             # per-view position-gradient statistics between backward and optimiser
@@ -348,8 +347,17 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    tune = (args.trainer == "native" and stepper.model.num_gaussians >= 1_000_000 and not getattr(args, "no_placement_tuning", False))
     for s in range(warmup):
         stepper.step(batch_for(s))
+        if tune and s == min(1, warmup - 1):
+            # Re-place the three [N,48] state tensors where that makes the optimiser's stream faster — AFTER the first steps, whose
+            # forward / backward make the library allocate its scratch (keys, ids, per-Gaussian projection rows, the 64-byte
+            # gradient rows): memory the compositing kernels gather from and scatter into.  Allocated behind the tuning's churn of
+            # gigabyte-sized allocations and frees, that scratch landed on memory where K6 / K7 ran 4 - 6 % slower in about half
+            # of the processes (bimodal: K6 0.553 / 0.578, K7 0.935 / 0.995 ms; interleaved runs on one box).
+            stepper.tune_placement(attempts=getattr(args, "placement_attempts", 4))
+            tune = False
     # the trainer's overlap probe times steps 2..9 in alternating forms and decides at step 10: never inside the timed region
     extra_warmup = 0
     while getattr(stepper, "probe_pending", False) and extra_warmup < 12:
@@ -362,13 +370,17 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     raster.collect_times()
     if hasattr(stepper, "phase_timing"):
         stepper.phase_timing = True
-    # start from a collected heap: a full (generation-2) collection of the Python heap is a 40 - 60 ms host pause in this process
-    # (seen at a fixed step of the run: 2.6 -> 4.3 ms/step over 30 steps); real training pays it once in thousands of steps
-    gc.collect()
+    # A full (generation-2) collection of this process's Python heap is a 40 - 60 ms host pause (seen at a fixed step of a run:
+    # 2.6 -> 4.3 ms/step over 30 steps); real training pays it once in thousands of steps.  gc.freeze() moves what exists now out of
+    # the collector's sight, so a collection inside the timed region only looks at the steps' own few objects.  (NOT gc.collect():
+    # freeing the set-up's garbage here changes which cached blocks torch hands to the per-step image tensors, and K6 / K7 ran 5 %
+    # slower on them — 2.55 -> 2.67 ms/step, interleaved runs on one box; the placement lottery of DESIGN §5 again.)
+    gc.freeze()
     t0 = time.perf_counter()
     for s in range(steps):
         stepper.step(batch_for(warmup + s))
     barrier()
+    gc.unfreeze()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
@@ -411,11 +423,12 @@ def run_drop_in(res, steps=8, warmup=3, optimizer_type="adam"):
         stepper.step(res["batch_for"](s))
     torch.cuda.synchronize(dev)
     res["tracer"].tracer_wrapper.collect_times()
-    gc.collect()
+    gc.freeze()
     t0 = time.perf_counter()
     for s in range(steps):
         stepper.step(res["batch_for"](warmup + s))
     torch.cuda.synchronize(dev)
+    gc.unfreeze()
     dt = time.perf_counter() - t0
     fb = res["tracer"].tracer_wrapper.collect_times()
     if optimizer_type == "selective_adam":
