@@ -317,7 +317,7 @@ class NativeTrainStep:
         way, virtual offsets inside one allocation do not matter, and ONE arena holding all seven (contiguous or interleaved by
         64-row blocks) always lands on the slow plateau.  So: time a no-op pass of the side-stream kernel over every row (zero
         learning rates, beta = 1: every value is rewritten with itself), then give each big tensor up to `attempts` fresh
-        allocations, round robin, until one move makes the pass > 3 % faster (the rates are bimodal: 1.76 - 1.78 against 1.50 -
+        allocations, round robin, until one move makes the pass > 5 % faster (the rates are bimodal: 1.76 - 1.78 against 1.50 -
         1.54 ms at 6 M Gaussians, so the first faster trial is the fast plateau and the search ends; with two attempts per tensor
         four processes in a row stayed on the slow plateau, with four the odds of that are small).  Values are untouched; transient
         memory is at most 3 x attempts copies of ONE [N,48] tensor (13.8 GB at 6 M Gaussians; the first version of this held
@@ -350,7 +350,7 @@ class NativeTrainStep:
             return e0.elapsed_time(e1) / reps
 
         self.activate()   # the activation rows are part of what the pass rewrites: make them valid first
-        times = [timed()]
+        times = [min(timed(), timed())]   # (the very first pass of a process can be a few percent slow)
         best = times[0]
         held = []         # rejected / replaced allocations stay alive until the end, so that a "fresh" allocation IS fresh
         found = False
@@ -364,7 +364,7 @@ class NativeTrainStep:
                 setattr(obj, name, old.clone())
                 t = timed()
                 times.append(t)
-                if t < 0.97 * best:
+                if t < 0.95 * best:   # the plateaus are 12 - 15 % apart; noise between passes on one placement is 1 - 3 %
                     best = t
                     held.append(old)
                     found = True

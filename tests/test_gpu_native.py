@@ -546,12 +546,12 @@ def test_placement_tuning_moves_the_state_without_changing_it():
     times = tuned.tune_placement(attempts=2)
     # the start + at most 2 per big tensor; the first trial that is > 3 % faster ends the search
     assert 2 <= len(times) <= 7 and all(t > 0 for t in times) and tuned.placement_trials_ms == times
-    assert all(t >= 0.97 * times[0] for t in times[1:-1])
+    assert all(t >= 0.95 * times[0] for t in times[1:-1])
     for k, v in state(tuned).items():
         assert torch.equal(v, before[k]), k
     moved = [k for k in ptrs if state(tuned)[k].data_ptr() != ptrs[k]]
     assert set(moved) <= {"features", "m48", "v48"} and len(moved) <= 1   # only one of the three [N,48] tensors is ever re-placed ...
-    assert bool(moved) == (min(times[1:]) < 0.97 * times[0])            # ... and only for a pass that got > 3 % faster
+    assert bool(moved) == (min(times[1:]) < 0.95 * times[0])            # ... and only for a pass that got > 5 % faster
     assert torch.equal(tuned.activate(), act_before)
     for st in steppers:
         b = to_batch(view, DEV); b.rgb_gt = gt
