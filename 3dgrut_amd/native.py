@@ -355,7 +355,7 @@ class NativeTrainStep:
         held = []         # rejected / replaced allocations stay alive until the end, so that a "fresh" allocation IS fresh
         found = False
         for _ in range(max(0, int(attempts))):       # round robin over the three tensors; the rates are bimodal, so the first
-            for obj, name in ((m, "features"), (self, "m48"), (self, "v48")):   # trial that is > 3 % faster ends the search
+            for obj, name in ((m, "features"), (self, "m48"), (self, "v48")):   # trial that is > 5 % faster ends the search
                 free_bytes, _ = torch.cuda.mem_get_info(dev)
                 old = getattr(obj, name)
                 if free_bytes < 2 * old.numel() * old.element_size():

@@ -544,7 +544,7 @@ def test_placement_tuning_moves_the_state_without_changing_it():
     ptrs = {k: v.data_ptr() for k, v in state(tuned).items()}
     act_before = tuned.activate().clone()
     times = tuned.tune_placement(attempts=2)
-    # the start + at most 2 per big tensor; the first trial that is > 3 % faster ends the search
+    # the start + at most 2 per big tensor; the first trial that is > 5 % faster ends the search
     assert 2 <= len(times) <= 7 and all(t > 0 for t in times) and tuned.placement_trials_ms == times
     assert all(t >= 0.95 * times[0] for t in times[1:-1])
     for k, v in state(tuned).items():
