@@ -138,10 +138,21 @@ __global__ __launch_bounds__(256) void k_ssim_finish(const float* __restrict__ p
     if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)inv_count);
 }
 
-// fused photometric loss: out3 = { lambda_l1 * L1 + lambda_ssim * (1 - SSIM), L1, SSIM }
-__global__ __launch_bounds__(256) void k_photometric_finish(const float* __restrict__ partial, const float* __restrict__ partial_l1,
-                                                           int n, float inv_count_ssim, float inv_count_l1, float lambda_l1,
-                                                           float lambda_ssim, float* __restrict__ out3) {
+// fused photometric loss: out3 = { lambda_l1 * L1 + lambda_ssim * (1 - SSIM), L1, SSIM } from the forward kernel's per-workgroup
+// partial sums (fixed summation order: the value does not depend on which workgroup finished when).  Not a launch of its own:
+// workgroup 0 of the BACKWARD kernel does it (the partials are complete when that kernel starts, and its other 12 k workgroups
+// run meanwhile) — a 16 us single-workgroup launch less on the step's critical path.
+struct FinishArgs {
+    const float* partial = nullptr;
+    const float* partial_l1 = nullptr;
+    int n = 0;
+    float inv_count_ssim = 0.f, inv_count_l1 = 0.f, lambda_l1 = 0.f, lambda_ssim = 0.f;
+    float* out3 = nullptr;   // nullptr: nothing to finish (gut_ssim_backward)
+};
+
+__device__ __forceinline__ void photometric_finish(const float* __restrict__ partial, const float* __restrict__ partial_l1,
+                                                   int n, float inv_count_ssim, float inv_count_l1, float lambda_l1,
+                                                   float lambda_ssim, float* __restrict__ out3) {
     __shared__ double red[2][4];
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -174,9 +185,11 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(ImgView v, ImgView v2, const f
                                                  const float* __restrict__ img2, const float* __restrict__ dm_dmu1,
                                                  const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
                                                  const float* __restrict__ upstream, float inv_count, float ssim_weight,
-                                                 float l1_weight, float* __restrict__ grad, uint32_t gx, uint32_t gy) {
+                                                 float l1_weight, float* __restrict__ grad, uint32_t gx, uint32_t gy, FinishArgs fin) {
     __shared__ float s[3][kPatch][kRowStride];
     __shared__ float h[3][kPatch][kSTile];
+    if (fin.out3 && blockIdx.x == 0 && blockIdx.z == 0)   // (block-uniform)
+        photometric_finish(fin.partial, fin.partial_l1, fin.n, fin.inv_count_ssim, fin.inv_count_l1, fin.lambda_l1, fin.lambda_ssim, fin.out3);
     const int c = blockIdx.z;
     int tx, ty;
     xcd_tile(blockIdx.x, gx, gy, &tx, &ty);
@@ -283,7 +296,7 @@ int gut_ssim_backward(void* stream, int32_t channels, int32_t height, int32_t wi
     const gut::ImgView v = make_view(channels, height, width, stride_c, stride_h, stride_w);
     const double count = (double)channels * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
     hipLaunchKernelGGL(gut::k_ssim_bwd, grid, dim3(256), 0, s, v, v, d_img1, d_img2, maps, maps + plane, maps + 2 * plane, d_upstream,
-                       (float)(1.0 / count), 0.0f, 0.0f, d_grad_img1, gx, gy);
+                       (float)(1.0 / count), 0.0f, 0.0f, d_grad_img1, gx, gy, gut::FinishArgs());
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -312,10 +325,12 @@ int gut_photometric_loss(void* stream, int32_t height, int32_t width, const floa
                        maps + 2 * plane, gx, gy);
     const double count = 3.0 * (height - 2 * gut::kHalo) * (width - 2 * gut::kHalo);
     const double numel = 3.0 * height * width;
-    hipLaunchKernelGGL(gut::k_photometric_finish, dim3(1), dim3(256), 0, s, partial, partial_l1, nblocks, (float)(1.0 / count),
-                       (float)(1.0 / numel), lambda_l1, lambda_ssim, d_loss3);
+    gut::FinishArgs fin;
+    fin.partial = partial; fin.partial_l1 = partial_l1; fin.n = nblocks;
+    fin.inv_count_ssim = (float)(1.0 / count); fin.inv_count_l1 = (float)(1.0 / numel);
+    fin.lambda_l1 = lambda_l1; fin.lambda_ssim = lambda_ssim; fin.out3 = d_loss3;
     hipLaunchKernelGGL(gut::k_ssim_bwd, grid, dim3(256), 0, s, v, g, d_rgba, d_gt_rgb, maps, maps + plane, maps + 2 * plane,
-                       (const float*)nullptr, (float)(1.0 / count), -lambda_ssim, (float)(lambda_l1 / numel), d_rgba_grad, gx, gy);
+                       (const float*)nullptr, (float)(1.0 / count), -lambda_ssim, (float)(lambda_l1 / numel), d_rgba_grad, gx, gy, fin);
     if (background != 0.0f) {
         const int pixels = height * width;
         hipLaunchKernelGGL(gut::k_alpha_grad, dim3((pixels + 255) / 256), dim3(256), 0, s, pixels, background, d_rgba_grad);
