@@ -516,7 +516,7 @@ class NativeTrainStep:
         gt = batch.rgb_gt
         if self.fused_loss and m.background_color in ("black", "white") and gt.dtype == torch.float32 and gt.is_contiguous() \
                 and gt.numel() == rgba.shape[0] * rgba.shape[1] * 3:
-            # loss value and d(loss)/d(rgba) in three HIP launches (csrc/gut_ssim.hip: gut_photometric_loss)
+            # loss value and d(loss)/d(rgba) in two HIP launches (csrc/gut_ssim.hip: gut_photometric_loss)
             H, W = rgba.shape[0], rgba.shape[1]
             need = self._lib.gut_photometric_workspace_bytes(H, W)
             if self._loss_ws is None or self._loss_ws.numel() * 4 < need:
