@@ -495,3 +495,68 @@ def test_mcmc_schedule_against_the_reference():
     assert mc.post_optimizer_step(600, 1e-4) == ["relocate", "add", "perturb"] == log
     assert mc.post_optimizer_step(601, 1e-4) == ["perturb"] and mc.post_optimizer_step(500, 1e-4) == ["perturb"]
     assert mc.post_optimizer_step(0, 1e-4) == [] and mc.post_optimizer_step(27500, 1e-4) == []
+
+
+def test_render_hands_over_the_models_two_feature_tensors(G, R):
+    """Tracer.render on a model with the reference's get_features_albedo / get_features_specular accessors (model.py:68-72) and a
+    wrapper that offers trace_model_fields: the two tensors go to _Autograd as they are (features_albedo in the mog_sph slot,
+    features_specular as the thirteenth argument, no get_features() call), the six gradients of trace_bwd_model_fields reach
+    the six leaves, and with tracer.split_features = False — or a wrapper without the entry point — the reference's call is made."""
+    t = lambda k: torch.as_tensor(G["ag_in_" + k]).clone()
+    n = int(G["ag_in_pos"].shape[0])
+    canned = {k: torch.as_tensor(G["ag_canned_" + k]) for k in ("rgba", "dist", "hits", "vis")}
+    grads = {k: torch.full((n, c), float(i + 1)) for i, (k, c) in enumerate((("pos", 3), ("dns", 1), ("rot", 4), ("scl", 3), ("alb", 3), ("spec", 45)))}
+
+    class Wrapper(_Raster):
+        def __init__(self, G):
+            super().__init__(G)
+            self.model_fields_args = self.model_fields_bwd_args = None
+
+        def trace_model_fields(self, *a):
+            self.model_fields_args = a
+            return tuple(canned[k].clone() for k in ("rgba", "dist", "hits", "vis"))
+
+        def trace_bwd_model_fields(self, *a):
+            self.model_fields_bwd_args = a
+            return tuple(grads[k] for k in ("pos", "dns", "rot", "scl", "alb", "spec"))
+
+    class Gaussians:
+        num_gaussians, n_active_features = n, 2
+        def __init__(self):
+            self.positions = t("pos").requires_grad_(True)
+            self.rot, self.scl, self.dns = (t(k).requires_grad_(True) for k in ("rot", "scl", "dns"))
+            sph = t("sph")
+            self.alb, self.spec = sph[:, :3].clone().requires_grad_(True), sph[:, 3:].clone().requires_grad_(True)
+            self.cat_calls = 0
+        def get_rotation(self): return self.rot
+        def get_scale(self): return self.scl
+        def get_density(self): return self.dns
+        def get_features_albedo(self): return self.alb
+        def get_features_specular(self): return self.spec
+        def get_features(self):
+            self.cat_calls += 1
+            return torch.cat((self.alb, self.spec), dim=1)
+        def background(self, T_to_world, rays_d, rgb, opacity, train): return rgb, opacity
+
+    c2w = torch.tensor(R["create_camera_parameters"]["c2w"], dtype=torch.float32).reshape(4, 4)
+    batch = gut.Batch(rays_ori=t("ray_ori"), rays_dir=t("ray_dir"), T_to_world=c2w[None], intrinsics=[100.0, 110.0, 3.5, 2.5])
+    tr = gut.Tracer.__new__(gut.Tracer)
+    tr.tracer_wrapper = Wrapper(G)
+    gs = Gaussians()
+    out = tr.render(gs, batch, train=True, frame_id=4)
+    a = tr.tracer_wrapper.model_fields_args
+    assert a is not None and tr.tracer_wrapper.trace_args is None and gs.cat_calls == 0
+    assert a[0] == 4 and a[1] == 2
+    for got, want in zip(a[2:8], (gs.positions, gs.dns, gs.rot, gs.scl, gs.alb, gs.spec)):   # pos, density, rotation, scale, albedo, specular
+        assert got.shape == want.shape and torch.equal(got.detach(), want.detach())
+    (out["pred_rgb"].sum() + out["pred_opacity"].sum()).backward()
+    b = tr.tracer_wrapper.model_fields_bwd_args
+    assert b is not None and b[0] == 4 and b[1] == 2 and b[2] == n
+    for leaf, k in ((gs.positions, "pos"), (gs.dns, "dns"), (gs.rot, "rot"), (gs.scl, "scl"), (gs.alb, "alb"), (gs.spec, "spec")):
+        assert torch.equal(leaf.grad, grads[k]), k
+    # the switch, and a wrapper with the pybind surface only: the reference's get_features() + trace()
+    for wrapper, split in ((Wrapper(G), False), (_Raster(G), True)):
+        tr.tracer_wrapper, tr.split_features = wrapper, split
+        gs = Gaussians()
+        tr.render(gs, batch, train=True, frame_id=5)
+        assert gs.cat_calls == 1 and wrapper.trace_args is not None and getattr(wrapper, "model_fields_args", None) is None
