@@ -118,3 +118,69 @@ def test_single_rank_record_exchange():
     assert ex.host_counts() == [3] and int(counts_dev[0]) == 3 and cap == 4 and torch.equal(gathered[0, :3], rec[:3]) and ex.tail(rec) is None
     dp.assert_replicas_identical([rec], 1)
     assert dp.collective_info(1)["world_size_seen"] == 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# densification under data parallelism (SURVEY §8e + N3): each rank accumulates the statistics of ITS view
+# (strategy/gs.py:106-115); GSStrategy.densify(world) adds them up over the ranks, and the clone / split that follows is
+# the same on every rank (children drawn from a generator seeded with (seed, step)): the replicas stay identical.
+# ---------------------------------------------------------------------------------------------------
+class _CpuStepper:
+    def __init__(self, model):
+        n = model.num_gaussians
+        self.model = model
+        g = torch.Generator().manual_seed(4)
+        self.m12, self.v12 = torch.randn((n, 12), generator=g) * 1e-3, torch.rand((n, 12), generator=g) * 1e-6
+        self.m48, self.v48 = torch.randn((n, 48), generator=g) * 1e-3, torch.rand((n, 48), generator=g) * 1e-6
+        self.post_backward_hook, self.row_listeners, self.step_id = None, [], 600
+
+    def resize_workspace(self):
+        pass
+
+
+def _densify_scene():
+    scenes = importlib.import_module("3dgrut_amd.scenes")
+    sc = scenes.scene_c1(300, 8)
+    sc["scale"][:150] = 0.001   # clone candidates
+    sc["scale"][150:] = 0.5     # split candidates
+    return sc
+
+
+def _view_grads(view, n=300):
+    g = torch.Generator().manual_seed(50 + view)
+    grad = torch.randn((n, 3), generator=g) * 10.0 ** torch.empty((n, 1)).uniform_(-5, -2, generator=g)
+    grad[torch.rand(n, generator=g) < 0.5] = 0.0
+    return grad, torch.tensor([0.5 * view, -1.0, 3.0 + view])
+
+
+def _densify_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    native = importlib.import_module("3dgrut_amd.native"); strategy = importlib.import_module("3dgrut_amd.strategy")
+    st = _CpuStepper(native.NativeGaussianModel(_densify_scene(), device="cpu"))
+    gs = strategy.GSStrategy(st, seed=11).attach()
+    for step in range(3):                                  # three steps, one view per rank and step
+        st.post_backward_hook(*_view_grads(dp.view_index(step, rank, world, 6)))
+    gs.densify(scene_extent=1.0, step=600, world=world)
+    torch.save(dict(raw=st.model.raw, features=st.model.features, m12=st.m12, v48=st.v48, n=st.model.num_gaussians),
+               os.path.join(out_dir, f"d{rank}.pt"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_densification_statistics_are_additive_and_replicas_stay_identical(tmp_path):
+    world = 2
+    mp.spawn(_densify_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"d{k}.pt")) for k in range(world)]
+    assert r[0]["n"] == r[1]["n"] > 300
+    for k in ("raw", "features", "m12", "v48"):
+        assert torch.equal(r[0][k], r[1][k]), k           # bit-identical replicas after clone + split
+    # one process that saw all six views' statistics densifies the same way
+    native = importlib.import_module("3dgrut_amd.native"); strategy = importlib.import_module("3dgrut_amd.strategy")
+    st = _CpuStepper(native.NativeGaussianModel(_densify_scene(), device="cpu"))
+    gs = strategy.GSStrategy(st, seed=11).attach()
+    for step in range(3):
+        for rank in range(world):
+            st.post_backward_hook(*_view_grads(dp.view_index(step, rank, world, 6)))
+    gs.densify(scene_extent=1.0, step=600, world=1)
+    assert st.model.num_gaussians == r[0]["n"]
+    assert torch.allclose(st.model.raw, r[0]["raw"], rtol=1e-6, atol=1e-7) and torch.equal(st.m12, r[0]["m12"])
