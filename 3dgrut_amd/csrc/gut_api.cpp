@@ -1124,6 +1124,25 @@ int gut_set_option(gut_handle h, int32_t option, int32_t value) {
         if (value < 0 || value > 100) return fail("gut_set_option: GUT_OPT_EARLY_EXTRA_PERCENT takes 0..100");
         h->early_extra_percent = value;
         return 0;
+    case GUT_OPT_DEBUG_REPLACE_SCRATCH: {
+        // developer probe (tools/scratch_placement.py): move ONE scratch buffer to a fresh allocation, contents kept
+        DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
+                          &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
+                          &h->sort_temp, &h->ids_ordered, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->tile_ordered};
+        const int count = (int)(sizeof(bufs) / sizeof(bufs[0]));
+        if (value < 0 || value >= count) return fail("gut_set_option: GUT_OPT_DEBUG_REPLACE_SCRATCH takes 0..%d", count - 1);
+        DevBuf& b = *bufs[value];
+        if (!b.p) return 0;
+        DeviceGuard dev_guard;
+        HIP_TRY(dev_guard.set(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        void* fresh = nullptr;
+        HIP_TRY(hipMalloc(&fresh, b.cap));          // the old allocation is still held: this one is somewhere else
+        HIP_TRY(hipMemcpy(fresh, b.p, b.cap, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipFree(b.p));
+        b.p = fresh;
+        return 0;
+    }
     default: return fail("gut_set_option: unknown option %d", option);
     }
 }

@@ -306,10 +306,9 @@ class NativeTrainStep:
 
     def tune_placement(self, attempts=4):
         """Re-place the three [N,48] state tensors (SH parameters and their two moments) in HBM where that makes the optimiser's
-        stream faster; call once after the first step or two of a run (NOT between building the model and the first step: the
-        library allocates its scratch in the first forward / backward, and behind this method's churn of gigabyte-sized
-        allocations that scratch landed on memory where the compositing kernels ran 4 - 6 % slower in half of the processes)
-        and again after densification / reorder, which re-allocate.
+        stream faster; call once after the first step or two of a run (the bench does; called between building the model and
+        the first step, the compositing kernels ran 4 - 6 % slower in half of the processes — DESIGN.md §5) and again after
+        densification / reorder, which re-allocate.
 
         On MI355X the rate at which the optimiser streams its seven tensors has two plateaus (measured on the 6 M-Gaussian bench
         scene: 5.2 and 5.9 TB/s for the same no-op pass, profiles/round3/placement_probe_*.log) decided by WHICH physical memory

@@ -473,6 +473,10 @@ class SplatRaster:
         hold no Gaussian the forward walked (GUT_OPT_EARLY_EXTRA_PERCENT, default 100; 0 = waves without tiles only)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_EARLY_EXTRA_PERCENT, int(percent)), "set_option")
 
+    def debug_replace_scratch(self, index):
+        """Developer probe: move one of the handle's scratch buffers to a fresh allocation (GUT_OPT_DEBUG_REPLACE_SCRATCH, gut_hip.h)."""
+        _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_DEBUG_REPLACE_SCRATCH, int(index)), "set_option")
+
     def set_sorted_reference_backward(self, on=True):
         """Sorted variant: the reference's own (unclamped-colour undo) form of the alpha gradient (default off; gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_SORTED_REFERENCE_BACKWARD, 1 if on else 0), "set_option")

@@ -351,11 +351,10 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     for s in range(warmup):
         stepper.step(batch_for(s))
         if tune and s == min(1, warmup - 1):
-            # Re-place the three [N,48] state tensors where that makes the optimiser's stream faster — AFTER the first steps, whose
-            # forward / backward make the library allocate its scratch (keys, ids, per-Gaussian projection rows, the 64-byte
-            # gradient rows): memory the compositing kernels gather from and scatter into.  Allocated behind the tuning's churn of
-            # gigabyte-sized allocations and frees, that scratch landed on memory where K6 / K7 ran 4 - 6 % slower in about half
-            # of the processes (bimodal: K6 0.553 / 0.578, K7 0.935 / 0.995 ms; interleaved runs on one box).
+            # Re-place the three [N,48] state tensors where that makes the optimiser's stream faster — after the first steps, when
+            # the library has allocated its scratch.  (With the tuning's churn of gigabyte-sized allocations BEFORE the first step
+            # the compositing kernels ran 4 - 6 % slower in half of the processes, interleaved runs on one box; no single buffer's
+            # placement explains it — DESIGN.md §5, "the compositors' speed wanders" — but this order has not shown it.)
             stepper.tune_placement(attempts=getattr(args, "placement_attempts", 4))
             tune = False
     # the trainer's overlap probe times steps 2..9 in alternating forms and decides at step 10: never inside the timed region
@@ -373,8 +372,8 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
     # A full (generation-2) collection of this process's Python heap is a 40 - 60 ms host pause (seen at a fixed step of a run:
     # 2.6 -> 4.3 ms/step over 30 steps); real training pays it once in thousands of steps.  gc.freeze() moves what exists now out of
     # the collector's sight, so a collection inside the timed region only looks at the steps' own few objects.  (NOT gc.collect():
-    # freeing the set-up's garbage here changes which cached blocks torch hands to the per-step image tensors, and K6 / K7 ran 5 %
-    # slower on them — 2.55 -> 2.67 ms/step, interleaved runs on one box; the placement lottery of DESIGN §5 again.)
+    # with it K6 / K7 ran 5 % slower in the loop that followed — 2.55 -> 2.67 ms/step, interleaved runs on one box; DESIGN.md §5,
+    # "the compositors' speed wanders".)
     gc.freeze()
     t0 = time.perf_counter()
     for s in range(steps):

@@ -246,6 +246,13 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * such waves cannot receive a gradient; their zero-gradient Adam step is the same arithmetic wherever it runs.  0 = only waves
  * without tiles take the side stream. */
 #define GUT_OPT_EARLY_EXTRA_PERCENT 3
+/* GUT_OPT_DEBUG_REPLACE_SCRATCH (developer probe, not a tuning knob): value = index of one of the handle's scratch buffers
+ * (0 tiles_count, 1 tiles_offset, 2 proj_pos, 3 conic_opacity, 4 extent, 5 depth, 6 feat, 7 gradient rows, 8 scan temp, 9 / 10
+ * unsorted / grouped keys, 11 / 12 unsorted / grouped ids, 13 sort temp, 14 ordered ids, 15 tile ranges, 16 / 17 traversal
+ * depths, 18 / 19 tile launch order / ordered prefix): the buffer moves to a fresh device allocation, contents kept (synchronises
+ * the device).  tools/scratch_placement.py uses it to find out whose physical placement the compositing kernels' two speeds
+ *  belong to. */
+#define GUT_OPT_DEBUG_REPLACE_SCRATCH 100
 int gut_set_option(gut_handle h, int32_t option, int32_t value);
 
 /* per-kernel hipEvent timings of the last trace / trace_bwd (ms), for bench.py's roofline block.
