@@ -22,7 +22,8 @@ st.tune_placement()
 for i in range(2, 14): st.step(batch(i))
 st.raster.kernel_times_mean()
 line = []
-for w in range(40):
+windows = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for w in range(windows):
     for i in range(10): st.step(batch(i))
     t, _ = st.raster.kernel_times_mean()
     line.append(f"{t['render']:.3f}/{t['render_bwd']:.3f}/{t['optimizer_early_2']:.2f}/{t['optimizer']:.3f}")
