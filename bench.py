@@ -407,7 +407,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
                 batch_for=batch_for, tracer=tracer, dev=dev)
 
 
-def run_drop_in(res, steps=8, warmup=3, optimizer_type="adam"):
+def run_drop_in(res, steps=16, warmup=5, optimizer_type="adam"):
     """The SAME workload through the reference's own surface, untouched trainer side: Tracer.render -> Tracer._Autograd ->
     torch loss -> loss.backward() -> torch.optim.Adam (3dgrut_amd/train.TrainStep = trainer.py:705-778 with only the renderer
     swapped).  This is what a user of threedgrut.trainer gets by switching the plugin; `value` above additionally needs the
