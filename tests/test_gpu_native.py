@@ -862,3 +862,29 @@ def test_train_step_with_the_selective_adam_option():
         assert not st["exp_avg"][~vis].any() and not st["exp_avg_sq"][~vis].any()
     with pytest.raises(ValueError):
         train_mod.TrainStep(steppers["adam"].model, gut.Tracer({"render": {}}), optimizer_type="lion")
+
+
+def test_scratch_buffers_can_be_moved_between_steps():
+    """GUT_OPT_DEBUG_REPLACE_SCRATCH (the developer probe behind tools/scratch_placement.py): every scratch buffer of the handle moves
+    to a fresh allocation between two train steps, contents kept — the library holds no stale pointer to any of them: the next
+    steps run, and the trainer ends where an undisturbed one ends (up to the float-atomic order of the backward)."""
+    sc = scenes.scene_c1(30000, 17)
+    W, H = 128, 96
+    views = [make_view("pinhole", W, H, cams.look_at_c2w((0.2 * k, 0.1, -3.0), (0, 0, 0)), fx=110.0) for k in range(3)]
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(9)).to(DEV)
+    ends = []
+    for disturb in (False, True):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+        st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, overlap_optimizer=True)
+        for k in range(6):
+            b = to_batch(views[k % 3], DEV); b.T_to_world = b.T_to_world.cpu(); b.rgb_gt = gt
+            st.step(b)
+            if disturb and k in (1, 3):
+                for idx in range(20):
+                    st.raster.debug_replace_scratch(idx)
+        st.sync_moments()
+        ends.append((model.raw.clone(), model.features.clone(), st.m48.clone()))
+    with pytest.raises(RuntimeError, match="GUT_OPT_DEBUG_REPLACE_SCRATCH"):
+        st.raster.debug_replace_scratch(20)
+    for a, b in zip(*ends):
+        assert bool(torch.isfinite(b).all()) and rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
