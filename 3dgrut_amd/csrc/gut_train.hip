@@ -315,6 +315,36 @@ __device__ __forceinline__ void adam4_zero_grad(const AdamParams& ap, const floa
 #undef GUT_ADAM_LANE
 }
 
+// The zero-gradient update of a wave whose moments are decayed lazily (read, never stored): with k1, k2 = beta^(steps missed)
+//     m' = (beta1 k1) m,   v' = (beta2 k2) v,   p -= lr m' / (sqrt(v') / bias2_sqrt + eps)
+// in 7 VALU instructions per value instead of 14 — this is the arithmetic of the side-stream pass, whose instructions issue on
+// the SIMDs of the VALU-bound compositing kernels next door, so every one of them is taken from K6 / K7.  The constant factors
+// are folded on the scalar side (c1 = beta1 k1; c2s = beta2 k2 2^32; b2s = 2^-16 / bias2_sqrt...) — the power of two lifts a
+// denormal second moment into the hardware square root's range without the compare-and-select of sqrt_approx_pos, and being a
+// power of two changes no bit of the result.  For a wave that is up to date (k = 1) the three values are those of adam4 with a
+// zero gradient, bit for bit (beta m + (1 - beta) 0 = beta m); for k > 1 the decay is one rounding of beta k instead of two of
+// the moment — inside the tolerance the lazy decay is specified with (deviation 10).  Every kernel that updates a
+// lazy wave uses THIS function (the side-stream pass and k_sh_adam's lazy branch): the one- and two-pass forms stay bit-identical.
+struct LazyAdam {
+    float c1, c2s, b2s, eps;
+};
+__device__ __forceinline__ LazyAdam make_lazy_adam(const AdamParams& ap, const float2& dk) {
+    LazyAdam la;
+    la.c1 = ap.beta1 * dk.x;
+    la.c2s = (ap.beta2 * dk.y) * 0x1p+32f;
+    la.b2s = ap.bias2_sqrt * 0x1p-16f;
+    la.eps = ap.eps;
+    return la;
+}
+__device__ __forceinline__ void adam4_lazy(const LazyAdam& la, const float4& lr, float4& p, const float4& m, const float4& v) {
+#define GUT_ADAM_LANE(X) p.X -= lr.X * (la.c1 * m.X) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(la.c2s * v.X) * la.b2s + la.eps);
+    GUT_ADAM_LANE(x)
+    GUT_ADAM_LANE(y)
+    GUT_ADAM_LANE(z)
+    GUT_ADAM_LANE(w)
+#undef GUT_ADAM_LANE
+}
+
 // kScratch = true (one view, no exchange): the per-Gaussian epilogue of the backward (K8c) is folded in — grad12 then points
 // at the renderer's 64-byte gradient rows [pos3, density, quat4, scale3, rgb3, pad2] w.r.t. the ACTIVATED parameters, which
 // are chained to the raw parameters here (the activations are recomputed from the raw row the optimiser loads anyway, with
@@ -350,6 +380,33 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
             const bool has_tiles = __ballot(i < sp.n && tiles_count[i] != 0) != 0ull;
             lazy_wave = !has_tiles || (sp.rule_walked && sp.rule_walked[wave_index] == 0);
         }
+    }
+    if (kScratch && lazy_wave) {
+        // (wave-uniform) no row of this wave can receive a gradient — its gradient rows are exactly zero and are not even read —:
+        // the arithmetic of the side-stream pass, value for value (adam4_lazy), so that the one-pass and two-pass forms agree bit
+        // for bit; the stored moments stay those of wave_step[wave]
+        const LazyAdam l12 = make_lazy_adam(sp.a12, dk), l48 = make_lazy_adam(sp.a48, dk);
+        if (i < sp.n) {
+            float4 a = p12[3 * (size_t)i + 0], b = p12[3 * (size_t)i + 1], c = p12[3 * (size_t)i + 2];
+            adam4_lazy(l12, make_float4(sp.a12.lr[0], sp.a12.lr[1], sp.a12.lr[2], sp.a12.lr[3]), a, m12[3 * (size_t)i + 0], v12[3 * (size_t)i + 0]);
+            adam4_lazy(l12, make_float4(sp.a12.lr[4], sp.a12.lr[5], sp.a12.lr[6], sp.a12.lr[7]), b, m12[3 * (size_t)i + 1], v12[3 * (size_t)i + 1]);
+            adam4_lazy(l12, make_float4(sp.a12.lr[8], sp.a12.lr[9], sp.a12.lr[10], sp.a12.lr[11]), c, m12[3 * (size_t)i + 2], v12[3 * (size_t)i + 2]);
+            p12[3 * (size_t)i + 0] = a; p12[3 * (size_t)i + 1] = b; p12[3 * (size_t)i + 2] = c;
+            if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
+        }
+        float4* bp = p48 + (size_t)wave_first * 12;
+        const float4* bm = m48 + (size_t)wave_first * 12;
+        const float4* bv = v48 + (size_t)wave_first * 12;
+#pragma unroll 4
+        for (int it = 0; it < 12; ++it) {
+            const uint32_t q = (uint32_t)it * 64u + lane;
+            if (q >= rows_here * 12u) continue;
+            const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
+            float4 pp = bp[q];
+            adam4_lazy(l48, make_float4(sp.a48.lr[col], sp.a48.lr[col + 1], sp.a48.lr[col + 2], sp.a48.lr[col + 3]), pp, bm[q], bv[q]);
+            bp[q] = pp;
+        }
+        return;
     }
     float G[48];
 #pragma unroll
@@ -490,6 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_sh_adam(ShAdamParams sp, float* __re
 // the pass is not latency-bound; two waves per SIMD at half the registers: same bytes, but scratch at the 64-VGPR bound;
 // skipping the stores of groups whose moments are all zero (fixed points of the update): the start of a training run 4 %
 // faster, its steady state 8 % slower (the test sits between the loads and their use).
+template <bool kLazy>   // kLazy: lazy moment decay (the moments are read, never stored) — uniform over the launch
 __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamParams a12, AdamParams a48, uint32_t n,
                                                                           const uint32_t* __restrict__ tiles_count,
                                                                           float4* __restrict__ p12, float4* __restrict__ m12,
@@ -524,7 +582,35 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
         // lazy moment decay: the moments are brought up to date in registers and NOT written back (the wave cannot receive a
         // gradient: its stored moments stay those of wave_step[wave], whoever reads them next decays them by the steps missed)
         const float2 dk = missed_decay(lazy, wave_first >> 6);
-        const bool store_mv = lazy.wave_step == nullptr;
+        // (kLazy == false: left a run-time value — with `true` known at compile time the schedule needs 88 VGPRs instead of 69, and
+        //  this kernel shares its SIMDs with the compositors' waves)
+        const bool store_mv = kLazy ? false : (lazy.wave_step == nullptr);
+        if (kLazy) {   // lazy moment decay: read p, m, v; write p and the activation row
+            const LazyAdam l12 = make_lazy_adam(a12, dk), l48 = make_lazy_adam(a48, dk);
+            if (mine) {
+                float4 a = p12[3 * (size_t)i + 0], b = p12[3 * (size_t)i + 1], c = p12[3 * (size_t)i + 2];
+                adam4_lazy(l12, make_float4(a12.lr[0], a12.lr[1], a12.lr[2], a12.lr[3]), a, m12[3 * (size_t)i + 0], v12[3 * (size_t)i + 0]);
+                p12[3 * (size_t)i + 0] = a;
+                adam4_lazy(l12, make_float4(a12.lr[4], a12.lr[5], a12.lr[6], a12.lr[7]), b, m12[3 * (size_t)i + 1], v12[3 * (size_t)i + 1]);
+                p12[3 * (size_t)i + 1] = b;
+                adam4_lazy(l12, make_float4(a12.lr[8], a12.lr[9], a12.lr[10], a12.lr[11]), c, m12[3 * (size_t)i + 2], v12[3 * (size_t)i + 2]);
+                p12[3 * (size_t)i + 2] = c;
+                if (act12) activate_row(a, b, c, act12 + 3 * (size_t)i);
+            }
+            float4* bp = p48 + (size_t)wave_first * 12;
+            const float4* bm = m48 + (size_t)wave_first * 12;
+            const float4* bv = v48 + (size_t)wave_first * 12;
+#pragma unroll 4
+            for (int it = 0; it < 12; ++it) {
+                const uint32_t q = (uint32_t)it * 64u + lane;
+                if (q >= rows_here * 12u) continue;
+                const uint32_t row = q / 12u, col = (q - row * 12u) * 4u;
+                float4 pp = bp[q];
+                adam4_lazy(l48, s_lr48[col >> 2], pp, bm[q], bv[q]);
+                bp[q] = pp;
+            }
+            continue;
+        }
         if (mine) {
             // one float4 of (p, m, v) at a time: at most 12 of the row's 36 values are live besides the updated parameters
             // the activation needs (the kernel must stay within 64 VGPRs WITHOUT scratch, see below)
@@ -726,7 +812,8 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
     }
     const uint32_t cap = (uint32_t)(second_launch ? wgs_per_cu2 : wgs_per_cu) * (uint32_t)num_cus;
     const uint32_t grid = nblocks < cap ? nblocks : cap;
-    hipLaunchKernelGGL(k_adam_rows_without_gradient, dim3(grid), dim3(kBlock), 0, s, a12, a48, n, tiles_count,
+    auto kern = lazy.wave_step ? k_adam_rows_without_gradient<true> : k_adam_rows_without_gradient<false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, a12, a48, n, tiles_count,
                        reinterpret_cast<float4*>(raw12), reinterpret_cast<float4*>(raw_m), reinterpret_cast<float4*>(raw_v),
                        reinterpret_cast<float4*>(sh48), reinterpret_cast<float4*>(sh_m), reinterpret_cast<float4*>(sh_v),
                        reinterpret_cast<float4*>(act12_out), block_begin, block_end, own, second_launch ? 1u : 0u, lazy);
