@@ -32,8 +32,14 @@ def _second_half(rows_by_name):
     state (every view seen once, so the Adam moments of the rows are what they are in the bench; and the first dispatch of a
     kernel with a spill area — K6 — can include the runtime's one-off scratch set-up, 0.54 -> 1.45 ms)."""
     out = []
+    kn = lambda name: name[0] if isinstance(name, tuple) else name
+    # the side-stream kernel has two instantiations: <true> (lazy moment decay: the train steps) and <false> (tune_placement's no-op
+    # passes, trainers that write their moments every step); when both ran, the steps are the <true> ones
+    lazy_steps = any(re.search(r"\bk_adam_rows_without_gradient<true>", kn(name)) for name in rows_by_name)
     for name, rows in rows_by_name.items():
-        kname = name[0] if isinstance(name, tuple) else name
+        kname = kn(name)
+        if lazy_steps and re.search(r"\bk_adam_rows_without_gradient<false>", kname):
+            continue
         if re.search(r"\bk_adam_rows_without_gradient\b", kname):
             out.extend(rows[-2:])   # two launches per step; the run also holds the no-op passes of tune_placement
             continue
