@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GUT_HIP_LIB", os.path.join(HERE, "libgut_hip.so"))  # override: dev experiments only
 
-GUT_ABI_VERSION = 4   # include/gut_hip.h: bumped on every struct / array-length / signature change
+GUT_ABI_VERSION = 5   # include/gut_hip.h: bumped on every struct / array-length / signature change
 GUT_NUM_KERNEL_TIMERS = 11
 BWD_RAW_PARAMETER_GRADS = 1
 BWD_COMPACT_RADIANCE_GRADS = 2

@@ -93,13 +93,16 @@ def fisheye_rays(W, H, fx, fy, cx=None, cy=None, radial=None, newton_iterations=
     return np.zeros((1, H, W, 3), np.float32), d.astype(np.float32)[None]
 
 
-def fisheye_intrinsics_dict(W, H, fx, fy, cx=None, cy=None):
+def fisheye_intrinsics_dict(W, H, fx, fy, cx=None, cy=None, radial=None, max_angle=None):
+    """radial: (k1..k4) of the forward polynomial (zeros when None, as the ScanNet++ loader passes them); max_angle: the
+    dataset rule (dataset_colmap.py:167-172) when None."""
     cx = W / 2 if cx is None else cx
     cy = H / 2 if cy is None else cy
     return dict(
         resolution=np.array([W, H], np.int64), shutter_type=ShutterType.GLOBAL,
         principal_point=np.array([cx, cy], np.float32), focal_length=np.array([fx, fy], np.float32),
-        radial_coeffs=np.zeros(4, np.float32), max_angle=float(fisheye_max_angle(W, H, fx, fy, cx, cy)),
+        radial_coeffs=np.zeros(4, np.float32) if radial is None else np.asarray(radial, np.float32)[:4].copy(),
+        max_angle=float(fisheye_max_angle(W, H, fx, fy, cx, cy) if max_angle is None else max_angle),
     )
 
 

@@ -144,7 +144,7 @@ struct gut_context {
     // writes the ids it consumed, in final order, to ids_ordered; the fully sorted lists exist only on debug request
     DevBuf ids_ordered, dbg_keys_sorted, dbg_ids_sorted;
     bool lazy_enabled = true;      // gut_set_option(GUT_OPT_LAZY_TILE_ORDER)
-    bool sorted_reference_bwd = false;  // gut_set_option(GUT_OPT_SORTED_REFERENCE_BACKWARD)
+    bool sorted_reference_bwd = true;   // gut_set_option(GUT_OPT_SORTED_REFERENCE_BACKWARD): the reference's form is the default
     bool lazy_order = false;       // this forward used the lazy order
     bool dbg_sorted_valid = false;
     // per-T
@@ -265,7 +265,8 @@ void build_consts(const GutConfig& cfg, gut::RenderConsts* c) {
     c->cov_dilation = 0.3f;   // threedgut.cuh:50
     const float D = 3.0f;
     const float lambda = cfg.ut_alpha * cfg.ut_alpha * (D + cfg.ut_kappa) - D;
-    c->ut_delta = sqrtf(cfg.ut_alpha * cfg.ut_alpha * (D + cfg.ut_kappa));
+    // GAUSSIAN_UT_DELTA is made by the reference's build script in double and rounded once (setup_3dgut.py:41-45, threedgut.cuh:70)
+    c->ut_delta = (float)sqrt((double)cfg.ut_alpha * (double)cfg.ut_alpha * (3.0 + (double)cfg.ut_kappa));
     c->ut_w0_mean = lambda / (D + lambda);
     c->ut_wi = 1.0f / (2.0f * (D + lambda));
     c->ut_w0_cov = lambda / (D + lambda) + (1.0f - cfg.ut_alpha * cfg.ut_alpha + cfg.ut_beta);

@@ -16,8 +16,8 @@
 //
 // Deviation: the reference's sorted BACKWARD reads the UNclamped precomputed colour while its forward composites
 // max(colour, 0) (gutKBufferRenderer.cuh:130 vs :161); that breaks its own undo recurrence whenever a colour
-// channel is negative.  Here forward and backward both use the clamped colour by default;
-// gut_set_option(GUT_OPT_SORTED_REFERENCE_BACKWARD, 1) switches the colour term of d(alpha) to the reference's formula.
+// channel is negative.  The library follows the reference's formula by default (GUT_OPT_SORTED_REFERENCE_BACKWARD = 1);
+// gut_set_option(GUT_OPT_SORTED_REFERENCE_BACKWARD, 0) selects the exact derivative of the forward (clamped colour in both passes).
 #include "gut_internal.h"
 #include "gut_render_common.h"
 

@@ -173,9 +173,10 @@ class SplatRaster:
         self.enable_kernel_timings = bool(cfg.enable_kernel_timings)
         _capi.check(self._lib.gut_create(C.byref(cfg), self.device_index, C.byref(self._handle)), "SplatRaster()")
         self._timings = {}
-        # extension key (not in the reference's configs): render.splat.sorted_reference_backward
-        if not isinstance(config, _capi.GutConfig) and bool(_conf_get(config, "render.splat.sorted_reference_backward", False)):
-            self.set_sorted_reference_backward(True)
+        # extension key (not in the reference's configs): render.splat.sorted_reference_backward, default true = the reference's
+        # own backward of the sorted variant; false = the exact derivative of the forward (DESIGN.md §3 deviation 6)
+        if not isinstance(config, _capi.GutConfig) and not bool(_conf_get(config, "render.splat.sorted_reference_backward", True)):
+            self.set_sorted_reference_backward(False)
 
     def __del__(self):
         try:
@@ -478,7 +479,7 @@ class SplatRaster:
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_DEBUG_REPLACE_SCRATCH, int(index)), "set_option")
 
     def set_sorted_reference_backward(self, on=True):
-        """Sorted variant: the reference's own (unclamped-colour undo) form of the alpha gradient (default off; gut_hip.h)."""
+        """Sorted variant: the reference's own (unclamped-colour undo) form of the alpha gradient (the default; off = the exact derivative of the forward; gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_SORTED_REFERENCE_BACKWARD, 1 if on else 0), "set_option")
 
     def stats(self):

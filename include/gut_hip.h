@@ -32,8 +32,9 @@ extern "C" {
  * GUT_NUM_KERNEL_TIMERS to 11 in round 2; 3: GutLazyMoments in the gut_optimize_* / gut_sh_adam_step_ex signatures, gut_sync_moments,
  * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev, gut_trace_fields / gut_trace_bwd_fields;
  * 4: gut_trace_model_fields / gut_trace_bwd_model_fields, gut_position_gradient_statistics, gut_set_position_gradient_statistics,
- * gut_mcmc_perturb). */
-#define GUT_ABI_VERSION 4
+ * gut_mcmc_perturb; 5: behaviour, not layout — GUT_OPT_SORTED_REFERENCE_BACKWARD defaults to 1, the reference's own form of the
+ * sorted variant's backward; the UT sigma-point spread is rounded from double like the reference's build script does). */
+#define GUT_ABI_VERSION 5
 
 typedef struct gut_context* gut_handle;
 
@@ -234,11 +235,12 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * depths and gradients are identical to the fully sorted path; GUT_BUF_ORDERED_IDS shows what was walked, GUT_BUF_SORTED_*
  * still return the reference's full lists (built on request).  0 restores the full radix sort. */
 #define GUT_OPT_LAZY_TILE_ORDER 1
-/* GUT_OPT_SORTED_REFERENCE_BACKWARD (default 0; sorted variant k_buffer_size > 0 only): compute the colour term of d(alpha) in
- * the backward exactly as the reference does — un-doing the back-to-front colour recurrence from the final colour with the
- * UNclamped precomputed colour (gutKBufferRenderer.cuh:127-131, shRadiativeParticles.slang:179-207) although the forward
- * composited max(colour, 0) (:159-161).  Identical to the default wherever no composited colour channel is negative; where one
- * is, the reference's gradient is not the derivative of its own forward (the default is).  For like-for-like comparisons. */
+/* GUT_OPT_SORTED_REFERENCE_BACKWARD (default 1 since ABI 5; sorted variant k_buffer_size > 0 only): compute the colour term of
+ * d(alpha) in the backward exactly as the reference does — un-doing the back-to-front colour recurrence from the final colour
+ * with the UNclamped precomputed colour (gutKBufferRenderer.cuh:127-131, shRadiativeParticles.slang:179-207) although the
+ * forward composited max(colour, 0) (:159-161).  0 = the exact derivative of the forward (clamped colour in both passes).  The
+ * two are identical wherever no composited colour channel is negative; where one is, the reference's gradient is not the
+ * derivative of its own forward — the library follows the reference by default and offers the corrected form as the option. */
 #define GUT_OPT_SORTED_REFERENCE_BACKWARD 2
 /* GUT_OPT_EARLY_EXTRA_PERCENT (default 100, 0..100; unsorted variant): share of the 256-row blocks in which the second launch of
  * gut_optimize_rows_without_gradient (queued when the backward compositor starts) also takes the 64-row waves that HAVE tiles

@@ -471,7 +471,8 @@ void oracle_project(const OracleParams* prm, const OracleCamera* cam, int W, int
     const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
     const float D = 3.0f;
     const float lambda = prm->ut_alpha * prm->ut_alpha * (D + prm->ut_kappa) - D;
-    const float delta_f = sqrtf(prm->ut_alpha * prm->ut_alpha * (D + prm->ut_kappa)); /* GAUSSIAN_UT_DELTA, setup_3dgut.py:41-45 */
+    /* GAUSSIAN_UT_DELTA: computed in double by the build script and rounded once (setup_3dgut.py:41-45, threedgut.cuh:70) */
+    const float delta_f = (float)sqrt((double)prm->ut_alpha * (double)prm->ut_alpha * (3.0 + (double)prm->ut_kappa));
     const float w0_mean = lambda / (D + lambda);
     const float wi = 1.0f / (2.0f * (D + lambda));
     const float w0_cov = lambda / (D + lambda) + (1.0f - prm->ut_alpha * prm->ut_alpha + prm->ut_beta);

@@ -9,6 +9,10 @@ scenes = importlib.import_module("3dgrut_amd.scenes")
 pose = importlib.import_module("3dgrut_amd.pose")
 
 
+# OpenCV-fisheye polynomial of a ScanNet++ DSLR's size (k1..k4 of delta = theta (1 + k1 theta^2 + ... + k4 theta^8))
+FISHEYE_DIST = dict(radial=[-0.03, -0.006, 0.001, -0.0003])
+
+
 def make_view(kind, W, H, c2w, fx=None, fy=None, distortion=None):
     """Returns dict(W,H,c2w,ro,rd,oracle_cam,intrinsics_kw) for kind in {'pinhole','pinhole_list','fisheye'}."""
     tq = pose.sensor_pose_from_c2w(c2w).T_world_sensors[0]
@@ -35,10 +39,13 @@ def make_view(kind, W, H, c2w, fx=None, fy=None, distortion=None):
         else:
             kw = dict(intrinsics_OpenCVPinholeCameraModelParameters=K)
     elif kind == "fisheye":
+        # distortion: dict(radial=(k1..k4)[, max_angle=...]) — the OpenCV-fisheye forward polynomial with non-zero coefficients
+        # (cameraProjections.cuh:105-128) and, optionally, a field-of-view clamp tighter than the dataset rule's
         fx = fx or 0.45 * W
         fy = fy or fx
-        ro, rd = cams.fisheye_rays(W, H, fx, fy)
-        K = cams.fisheye_intrinsics_dict(W, H, fx, fy)
+        radial = None if not distortion else distortion.get("radial")
+        ro, rd = cams.fisheye_rays(W, H, fx, fy, radial=radial)
+        K = cams.fisheye_intrinsics_dict(W, H, fx, fy, radial=radial, max_angle=None if not distortion else distortion.get("max_angle"))
         ocam = dict(model="fisheye", principal_point=K["principal_point"], focal_length=K["focal_length"],
                     radial=list(K["radial_coeffs"]), max_angle=K["max_angle"], pose_start=tq)
         kw = dict(intrinsics_OpenCVFisheyeCameraModelParameters=K)
@@ -165,3 +172,28 @@ def check_side_stream_rows_are_gradient_free(owned_rows, g12, g48, dens_g, sph_g
         bad = np.abs(np.asarray(arr)[owned]).max(axis=1) > 0
         assert not bad.any(), f"{label}: {what} has {int(bad.sum())} non-zero rows among the {int(owned.sum())} rows of side-stream waves"
     print(f"[side-stream rows {label}] {int(owned.sum())} rows in side-stream waves, oracle and GPU gradients exactly zero on all of them")
+
+
+def fisheye_max_angle_edge_case(ulps_above=0):
+    """SURVEY §8c's known-answer case "fisheye theta == max_angle": a distorted OpenCV-fisheye camera at the world origin with the
+    identity pose (camera space = world space, exactly) whose max_angle is the fp32 value atan2f(rho, z) of Gaussian 0's centre
+    (plus `ulps_above` ulps).  Gaussian 0 is opaque and degenerate (scale 1e-12: all seven sigma points round to its centre), so it
+    lives or dies by the comparison `theta < max_angle` alone (cameraProjections.cuh:119,127: theta = min(thetaFull, maxAngle),
+    valid iff theta < maxAngle): with ulps_above = 0 every sigma point is invalid and the Gaussian gets no tile, one ulp above it
+    is valid and gets one.  The other Gaussians straddle the cone.  Returns (scene, view, theta_star)."""
+    import importlib
+    oracle = importlib.import_module("oracle.oracle")
+    sc = scenes.scene_c1(400, 21)
+    sc["positions"][:, 2] += np.float32(2.2)
+    x, y, z = np.float32(0.4), np.float32(0.3), np.float32(1.0)
+    sc["positions"][0] = (x, y, z)
+    sc["scale"][0] = 1e-12
+    sc["density"][0] = 0.999
+    rho = np.sqrt(np.float32(x * x) + np.float32(y * y), dtype=np.float32)
+    theta = np.float32(oracle.lib().oracle_det_atan2f(float(rho), float(z)))
+    for _ in range(ulps_above):
+        theta = np.nextafter(theta, np.float32(4.0))
+    W, H = 144, 96
+    view = make_view("fisheye", W, H, np.eye(4, dtype=np.float32), distortion=dict(FISHEYE_DIST, max_angle=float(theta)))
+    assert np.float32(view["oracle_cam"]["max_angle"]) == theta
+    return sc, view, float(theta)

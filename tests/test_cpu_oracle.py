@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import cams, make_view, pose, scenes
+from tests.common import FISHEYE_DIST, cams, fisheye_max_angle_edge_case, make_view, pose, scenes
 
 oracle = importlib.import_module("oracle.oracle")
 prt = importlib.import_module("oracle.per_ray_torch")
@@ -77,6 +77,29 @@ def test_culling_rules():
     res = {k: oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(v), v["features"], view["ro"], view["rd"])["tiles_count"][0]
            for k, v in cases.items()}
     assert res["low_opacity"] == 0 and res["behind_near"] == 0 and res["outside_margin"] == 0 and res["ok"] >= 1
+
+
+def test_fisheye_theta_equal_to_max_angle_is_invalid_one_ulp_above_is_valid():
+    """SURVEY §8c KAT: OpenCV fisheye, theta == max_angle (cameraProjections.cuh:119,127: theta = min(thetaFull, maxAngle), the
+    projection is valid iff theta < maxAngle).  A degenerate opaque Gaussian whose seven sigma points all sit at exactly
+    theta == max_angle gets no tile; with max_angle one fp32 ulp larger it is projected (non-zero polynomial coefficients) and
+    gets its tile at the closed-form position f * p.xy * theta (1 + k1 t^2 + k2 t^4 + k3 t^6 + k4 t^8) / rho + pp."""
+    out = {}
+    for ulps in (0, 1):
+        sc, view, theta = fisheye_max_angle_edge_case(ulps)
+        out[ulps] = oracle.forward(view["oracle_cam"], 144, 96, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    assert out[0]["tiles_count"][0] == 0 and out[0]["visibility"][0] == 0
+    assert out[1]["tiles_count"][0] == 1 and out[1]["visibility"][0] == 1
+    k1, k2, k3, k4 = FISHEYE_DIST["radial"]
+    t2 = theta * theta
+    delta = theta * (1.0 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)))) / 0.5
+    fx = 0.45 * 144
+    assert np.abs(out[1]["proj_pos"][0] - (fx * 0.4 * delta + 72.0, fx * 0.3 * delta + 48.0)).max() <= 2e-4
+    # the cone cuts through the other Gaussians too: some lose tiles against the dataset rule's max_angle, none gains one
+    sc, view, _ = fisheye_max_angle_edge_case(0)
+    wide = dict(view["oracle_cam"], max_angle=1.3)
+    ref_wide = oracle.forward(wide, 144, 96, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    assert ref_wide["M"] > out[0]["M"] > 100
 
 
 def test_structural_invariants_and_pad_aliasing():

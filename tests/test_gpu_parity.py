@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import cams, make_view, rel_l2, scenes, to_batch
+from tests.common import FISHEYE_DIST, cams, check_colour_outliers, fisheye_max_angle_edge_case, make_view, rel_l2, scenes, to_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +32,13 @@ CASES = {
     "ragged_100x70": (lambda: scenes.scene_c1(700, 3), "pinhole", 100, 70, ((0.5, -0.3, -3.0), (0, 0.1, 0)), dict(fx=90, fy=95)),
     "distorted_pinhole": (lambda: scenes.scene_c1(800, 4), "pinhole", 160, 96, ((0.2, 0.1, -3.2), (0, 0, 0)), dict(fx=120, distortion=DIST)),
     "fisheye_144x96": (lambda: scenes.scene_c1(900, 5), "fisheye", 144, 96, ((0.1, 0.0, -1.5), (0, 0, 0.5)), dict()),
+    # non-zero OpenCV-fisheye polynomial (cameraProjections.cuh:105-128; the COLMAP loader passes the camera's k1..k4,
+    # dataset_colmap.py:165-177): the Horner chain of project_fisheye multiplies real coefficients
+    "fisheye_distorted": (lambda: scenes.scene_c1(900, 12), "fisheye", 144, 96, ((0.1, 0.0, -1.5), (0, 0, 0.5)), dict(distortion=FISHEYE_DIST)),
+    # ... and with a field-of-view clamp INSIDE the image (max_angle 0.55 rad against the dataset rule's 1.34): sigma points beyond the
+    # cone are projected with the clamped angle and marked invalid, Gaussians straddle the cone
+    "fisheye_clamped_cone": (lambda: scenes.scene_c1(900, 13), "fisheye", 144, 96, ((0.1, 0.0, -1.5), (0, 0, 0.5)),
+                             dict(distortion=dict(FISHEYE_DIST, max_angle=0.55))),
     "inside_cloud": (lambda: scenes.scene_c1(1500, 6), "pinhole", 96, 96, ((0.05, 0.02, -0.1), (0, 0, 1)), dict(fx=60)),
     "dense_big_splats": (lambda: _big(), "pinhole", 64, 64, ((0, 0, -3), (0, 0, 0)), dict(fx=64)),
 }
@@ -155,7 +162,8 @@ def test_forward_buffers_and_image(name):
     assert st["traversed_fwd"] == ref["traversed_fwd"]
 
 
-@pytest.mark.parametrize("name", ["c1_pinhole_128", "ragged_100x70", "fisheye_144x96", "dense_big_splats", "inside_cloud"])
+@pytest.mark.parametrize("name", ["c1_pinhole_128", "ragged_100x70", "fisheye_144x96", "fisheye_distorted", "fisheye_clamped_cone",
+                                  "dense_big_splats", "inside_cloud"])
 @pytest.mark.parametrize("with_dist_grad", [False, True])
 def test_backward_gradients(name, with_dist_grad):
     mk, kind, W, H, (eye, tgt), kw = CASES[name]
@@ -254,15 +262,122 @@ def test_error_behaviour():
         raster.trace(0, 3, d12, sph, ro, rd, None, sensor, 0, 1, poses.T_world_sensors[0], poses.T_world_sensors[1])
 
 
+# every render.* / render.splat.* key gut_create ACCEPTS away from its render/3dgut.yaml default (the reference turns them into -D
+# defines, setup_3dgut.py:47-70): conf -> (oracle parameter overrides).  What gut_create rejects is tested in test_error_behaviour
+# and tests/test_cpu_host.py.
+TOGGLES = {
+    "global_z_order_off": ({"splat": {"global_z_order": False}}, dict(global_z_order=0)),                  # gutProjector.cuh:315-321
+    "rect_bounding_off": ({"splat": {"rect_bounding": False}}, dict(rect_bounding=0)),                     # :110-114
+    "tight_opacity_bounding_off": ({"splat": {"tight_opacity_bounding": False}}, dict(tight_opacity_bounding=0)),   # :100-108
+    "tile_based_culling_off": ({"splat": {"tile_based_culling": False}}, dict(tile_culling=0)),            # :279-293, :361-375
+    "all_bounding_and_culling_off": ({"splat": {"rect_bounding": False, "tight_opacity_bounding": False, "tile_based_culling": False,
+                                                "global_z_order": False}},
+                                     dict(rect_bounding=0, tight_opacity_bounding=0, tile_culling=0, global_z_order=0)),
+    "ut_half_alpha": ({"splat": {"ut_alpha": 0.5, "ut_beta": 1.0, "ut_kappa": 1.0}}, dict(ut_alpha=0.5, ut_beta=1.0, ut_kappa=1.0)),   # :150-201
+    "ut_wide_spread_and_margin": ({"splat": {"ut_alpha": 1.25, "ut_beta": 2.5, "ut_kappa": 0.5, "ut_in_image_margin_factor": 0.3}},
+                                  dict(ut_alpha=1.25, ut_beta=2.5, ut_kappa=0.5, ut_margin=0.3)),
+    "thresholds": ({"particle_kernel_min_response": 0.05, "particle_kernel_min_alpha": 0.01, "particle_kernel_max_alpha": 0.9,
+                    "min_transmittance": 0.01},
+                   dict(min_kernel_density=0.05, alpha_threshold=0.01, max_alpha=0.9, min_transmittance=0.01)),
+    "thresholds_loose": ({"particle_kernel_min_response": 0.002, "particle_kernel_min_alpha": 0.001, "particle_kernel_max_alpha": 0.999,
+                          "min_transmittance": 1e-6},
+                         dict(min_kernel_density=0.002, alpha_threshold=0.001, max_alpha=0.999, min_transmittance=1e-6)),
+}
+
+
+@pytest.mark.parametrize("toggle", list(TOGGLES))
+@pytest.mark.parametrize("name", ["c1_pinhole_128", "fisheye_distorted", "dense_big_splats"])
+def test_config_toggles_against_the_oracle(name, toggle):
+    """The configuration keys the library accepts away from their defaults reach the kernels as run-time constants
+    (gut_api.cpp: build_consts; the reference compiles a variant per configuration).  Each is checked like the default variant:
+    integer buffers and projection floats bit-exact, image 2e-4, gradients 2e-3 per block, traversal counts equal — and the key must
+    really change the result (the oracle's result with it differs from the default's)."""
+    mk, kind, W, H, (eye, tgt), kw = CASES[name]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    conf, overrides = TOGGLES[toggle]
+    prm = oracle.default_params()
+    for k, v in overrides.items():
+        assert hasattr(prm, k), k
+        setattr(prm, k, v)
+    model, d12, sph = _oracle_inputs(sc, 3)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3, params=prm)
+    ref0 = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    assert ref["M"] > 0
+    changed = (ref["M"] != ref0["M"] or not np.array_equal(ref["sorted_keys"], ref0["sorted_keys"]) or not np.array_equal(ref["rgba"], ref0["rgba"])
+               or not np.array_equal(ref["proj_pos"], ref0["proj_pos"]) or not np.array_equal(ref["extent"], ref0["extent"]))
+    assert changed, f"{toggle} changes nothing on {name}: the case does not test it"
+    rng = np.random.default_rng(17)
+    rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
+    dist_grad = (0.1 * rng.normal(size=(H, W, 1))).astype(np.float32)
+    dens_g, sph_g, _ = oracle.backward(view["oracle_cam"], ref, rgba_grad, dist_grad, params=prm)
+    tr = gut.Tracer({"render": conf})
+    out = tr.render(model, to_batch(view, DEV), train=True, frame_id=0)
+    raster = tr.tracer_wrapper
+    st = raster.stats()
+    assert st["num_intersections"] == ref["M"] and st["num_visible"] == int((ref["tiles_count"] > 0).sum())
+    for key in ("tiles_count", "tiles_offset", "unsorted_ids", "sorted_ids"):
+        assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
+    for key in ("unsorted_keys", "sorted_keys"):
+        assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint64), ref[key]), key
+    assert np.array_equal(raster.debug_buffer("tile_ranges").cpu().numpy().view(np.uint32).reshape(-1, 2), ref["tile_ranges"])
+    _check_ordered_ids(raster, ref)
+    for key in ("proj_pos", "conic_opacity", "extent", "depth", "feat"):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
+        exp = np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)
+        assert np.array_equal(got, exp), f"{key}: {(got != exp).sum()} of {got.size} words differ"
+    rgba = np.concatenate([out["pred_rgb"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
+    margins = oracle.render_margins(view["oracle_cam"], ref, params=prm)
+    check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"{name}/{toggle}", max_prone=0.2)
+    assert st["traversed_fwd"] == ref["traversed_fwd"]
+    rg = torch.as_tensor(rgba_grad, device=DEV)
+    loss = (out["pred_rgb"][0] * rg[..., :3]).sum() + (out["pred_opacity"][0] * rg[..., 3:]).sum() + \
+           (out["pred_dist"][0] * torch.as_tensor(dist_grad, device=DEV)).sum()
+    loss.backward()
+    for k, e in _activated_grads(model, dens_g, sph_g).items():
+        err = rel_l2(getattr(model, k).grad.cpu().numpy(), e)
+        assert err <= 2e-3, f"{name}/{toggle}/{k}: rel L2 {err}"
+    assert raster.stats()["traversed_bwd"] == ref["traversed_bwd"]
+
+
+@pytest.mark.parametrize("ulps_above", [0, 1])
+def test_fisheye_theta_equal_to_max_angle(ulps_above):
+    """SURVEY §8c KAT on the device: OpenCV fisheye with non-zero polynomial coefficients and max_angle == the fp32 atan2f of a
+    degenerate opaque Gaussian's direction (tests/common.fisheye_max_angle_edge_case; cameraProjections.cuh:119,127).  At equality
+    the Gaussian gets no tile, one ulp above it gets one — on the GPU exactly as in the oracle — and every integer buffer and
+    projection float of the frame (the cone cuts through the other Gaussians) is bit-identical."""
+    sc, view, theta = fisheye_max_angle_edge_case(ulps_above)
+    W, H = view["W"], view["H"]
+    model, d12, sph = _oracle_inputs(sc, 3)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    assert ref["tiles_count"][0] == ulps_above and ref["visibility"][0] == ulps_above
+    res = _run_gpu(sc, view, 3, model=model)
+    raster = res["tracer"].tracer_wrapper
+    for key in ("tiles_count", "tiles_offset", "unsorted_ids", "sorted_ids"):
+        assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
+    for key in ("unsorted_keys", "sorted_keys"):
+        assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint64), ref[key]), key
+    for key in ("proj_pos", "conic_opacity", "extent", "depth", "feat"):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)), key
+    vis = res["out"]["mog_visibility"].detach().cpu().numpy()[:, 0]
+    assert np.array_equal(vis > 0, ref["visibility"] > 0) and bool(vis[0] > 0) == bool(ulps_above)
+    rgb = res["out"]["pred_rgb"][0].detach().cpu().numpy()
+    assert np.abs(rgb - ref["rgba"][..., :3]).max() <= 2e-4
+
+
 @pytest.mark.parametrize("shutter", [0, 1, 2, 3])
-@pytest.mark.parametrize("kind", ["pinhole", "fisheye"])
+@pytest.mark.parametrize("kind", ["pinhole", "fisheye", "fisheye_distorted"])
 def test_rolling_shutter_projection(shutter, kind):
     """projectPointWithShutter<5> with distinct start/end poses (cameraProjections.cuh:146-185): tile/key buffers and
     projection floats stay bit-exact (slerp uses the shared deterministic acos/sin), image within tolerance."""
     pose_mod = importlib.import_module("3dgrut_amd.pose")
     sc = scenes.scene_c1(700, 40 + shutter)
     W, H = 96, 80
-    view = make_view(kind, W, H, cams.look_at_c2w((0.1, 0.0, -3.0 if kind == "pinhole" else -1.6), (0, 0, 0)), fx=90 if kind == "pinhole" else None)
+    distortion = FISHEYE_DIST if kind == "fisheye_distorted" else None
+    kind = "fisheye" if distortion else kind
+    view = make_view(kind, W, H, cams.look_at_c2w((0.1, 0.0, -3.0 if kind == "pinhole" else -1.6), (0, 0, 0)), fx=90 if kind == "pinhole" else None,
+                     distortion=distortion)
     end_c2w = cams.look_at_c2w((0.25, -0.1, -2.9 if kind == "pinhole" else -1.55), (0.05, 0.0, 0.0))
     tq_end = pose_mod.sensor_pose_from_c2w(end_c2w).T_world_sensors[0]
     ocam = dict(view["oracle_cam"], shutter=shutter, pose_end=tq_end)
@@ -301,8 +416,11 @@ def test_timings_surface():
 # ---------------------------------------------------------------------------------------------------
 # sorted variant (render.splat.k_buffer_size > 0), SURVEY §8a row a14
 # ---------------------------------------------------------------------------------------------------
-def _run_sorted(view, model, K, rgba_grad=None, dist_grad=None, reference_backward=False):
-    tr = gut.Tracer({"render": {"splat": {"k_buffer_size": K, "sorted_reference_backward": reference_backward}}})
+def _run_sorted(view, model, K, rgba_grad=None, dist_grad=None, reference_backward=None):
+    splat = {"k_buffer_size": K}
+    if reference_backward is not None:          # None: the library's default (the reference's form since ABI 5)
+        splat["sorted_reference_backward"] = reference_backward
+    tr = gut.Tracer({"render": {"splat": splat}})
     out = tr.render(model, to_batch(view, DEV), train=True, frame_id=0)
     if rgba_grad is not None:
         rg = torch.as_tensor(rgba_grad, device=DEV)
@@ -375,7 +493,7 @@ def test_sorted_variant_backward(name, with_dist_grad):
     dens_g[:, 4:8] = params["rotation"].grad.numpy()
     dens_g[:, 8:11] = params["scale"].grad.numpy()
     exp = _activated_grads(model, dens_g, params["features"].grad.numpy())
-    _run_sorted(view, model, K, rgba_grad=rgba_grad, dist_grad=dist_grad)
+    _run_sorted(view, model, K, rgba_grad=rgba_grad, dist_grad=dist_grad, reference_backward=False)   # the exact-derivative option
     for k, e in exp.items():
         g = getattr(model, k).grad.cpu().numpy()
         err = rel_l2(g, e)
@@ -419,11 +537,11 @@ def test_sorted_variant_reference_backward(name):
     # the two forms differ on the geometry / density gradients (not on the colour gradient) of this scene ...
     assert rel_l2(grads[True]["density"], grads[False]["density"]) > 1e-2
     assert rel_l2(grads[True]["features_albedo"], grads[False]["features_albedo"]) <= 1e-12
-    # ... and the kernel follows whichever is selected
-    for mode in (False, True):
+    # ... and the kernel follows whichever is selected; with nothing selected it follows the REFERENCE (ABI 5)
+    for mode in (False, True, None):
         model.zero_grad(set_to_none=True)
         _run_sorted(view, model, K, rgba_grad=rgba_grad, reference_backward=mode)
-        for k, e in grads[mode].items():
+        for k, e in grads[True if mode is None else mode].items():
             g = getattr(model, k).grad.cpu().numpy()
             assert rel_l2(g, e) <= 2e-3, f"{name}/{k} reference_backward={mode}: rel L2 {rel_l2(g, e)}"
 
