@@ -744,7 +744,57 @@ static Ray make_ray(const PoseSet* ps, const float* ro, const float* rd) {
 /* per-(ray, particle) response — slang/models/gaussianParticles.slang:96-222 */
 typedef struct { float gro[3], grdu[3], grd[3], gposc[3], gposcr[3], rdr[3], d2, resp, alpha; } Hit;
 
+/* Second, DIFFERENT BUT EQUALLY VALID fp32 evaluation of the same per-pair formulas (tests only: oracle_set_variant(1)) — the
+ * form the HIP compositors use (gut_render.hip): the rows of diag(1/s) * rotationT rounded once, fused multiply-adds, the
+ * response as |u x o|^2 / |u|^2 with one reciprocal (u = the UNnormalised canonical direction), exp2 of the pre-scaled
+ * argument.  It follows no reference line that variant 0 does not follow; it exists so that the tolerance of the GPU parity
+ * tests can be MEASURED as |variant 0 - variant 1| instead of estimated (tests/test_cpu_oracle.py, tests/common.py). */
+static int g_variant = 0;   /* 0: the reference's operation order; 1: fused form; 2: fused form with 1-ulp transcendentals */
+void oracle_set_variant(int v) { g_variant = v; }
+int oracle_get_variant(void) { return g_variant; }
+
+/* variant 2: the hardware's v_rcp_f32 / v_rsq_f32 / v_exp_f32 are specified to 1 ulp, not correctly rounded: move a correctly
+ * rounded result by -1, 0 or +1 ulp, chosen by a hash of its bits (deterministic, about a third each) */
+static float ulp_jitter(float x) {
+    if (g_variant != 2 || !(x > 0.0f) || !(x < 3.0e38f)) return x;
+    uint32_t b; memcpy(&b, &x, 4);
+    uint32_t hsh = b * 2654435761u; hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+    const uint32_t r = hsh % 3u;
+    b += (r == 1u) ? 1u : (r == 2u ? 0xFFFFFFFFu : 0u);
+    memcpy(&x, &b, 4);
+    return x;
+}
+
+static void eval_hit_fused(const OracleParams* prm, const float* g, const float rows[3][3], const Ray* ray, Hit* h) {
+    const float* mu = g; const float* s = g + 8; const float sigma = g[3];
+    float is[3], m[3][3];
+    for (int k = 0; k < 3; ++k) {
+        is[k] = ulp_jitter(1.0f / s[k]);
+        for (int j = 0; j < 3; ++j) m[k][j] = is[k] * rows[k][j];
+        h->gposc[k] = ray->o[k] - mu[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+        h->gposcr[k] = fmaf(rows[k][0], h->gposc[0], fmaf(rows[k][1], h->gposc[1], rows[k][2] * h->gposc[2]));
+        h->rdr[k] = fmaf(rows[k][0], ray->d[0], fmaf(rows[k][1], ray->d[1], rows[k][2] * ray->d[2]));
+        h->gro[k] = fmaf(m[k][0], h->gposc[0], fmaf(m[k][1], h->gposc[1], m[k][2] * h->gposc[2]));
+        h->grdu[k] = fmaf(m[k][0], ray->d[0], fmaf(m[k][1], ray->d[1], m[k][2] * ray->d[2]));
+    }
+    const float l2 = fmaf(h->grdu[0], h->grdu[0], fmaf(h->grdu[1], h->grdu[1], h->grdu[2] * h->grdu[2]));
+    const float il = l2 > 0.0f ? ulp_jitter(1.0f / sqrtf(l2)) : 1.0f;
+    for (int k = 0; k < 3; ++k) h->grd[k] = h->grdu[k] * il;
+    /* |u x o|^2 / |u|^2 */
+    const float c0 = fmaf(h->grdu[1], h->gro[2], -(h->grdu[2] * h->gro[1]));
+    const float c1 = fmaf(h->grdu[2], h->gro[0], -(h->grdu[0] * h->gro[2]));
+    const float c2 = fmaf(h->grdu[0], h->gro[1], -(h->grdu[1] * h->gro[0]));
+    const float n2 = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
+    h->d2 = l2 > 0.0f ? n2 * ulp_jitter(1.0f / l2) : 0.0f;   /* zero direction: grd = 0, as in variant 0 */
+    h->resp = ulp_jitter(exp2f(-0.72134752f * h->d2));
+    const float a = h->resp * sigma;
+    h->alpha = a < prm->max_alpha ? a : prm->max_alpha;
+}
+
 static void eval_hit(const OracleParams* prm, const float* g, const float rows[3][3], const Ray* ray, Hit* h) {
+    if (g_variant != 0) { eval_hit_fused(prm, g, rows, ray, h); return; }
     const float* mu = g; const float* s = g + 8; const float sigma = g[3];
     for (int k = 0; k < 3; ++k) h->gposc[k] = ray->o[k] - mu[k];
     for (int k = 0; k < 3; ++k) {
@@ -1026,8 +1076,19 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                 const float depth_g = dist_grad[pix];
                 /* flip budget, first pass over the ray: the summed alpha share of its flip-prone decisions */
                 float taint = 0.0f;
+                /* (round 4) ... and what the first pass learns about the ray as a whole:
+                 *  - chain noise: every later quantity of the ray inherits the fp32 noise of the alphas in front of it.  tn = the
+                 *    relative noise of the running transmittance in eps units (as t_noise below); nrgb_total[c] = the absolute
+                 *    noise, in eps units, of the final colour, sum_j w_j f_jc (nu_j + tn_j); tn_final that of the final T.
+                 *  - termination flip: if the running transmittance comes within flip_bound noise widths of min_transmittance
+                 *    the ray may end there or walk on in another evaluation, and then EVERY entry in front of that point sees
+                 *    different finals (the reference's residual form feeds T_final and rgb_final back into every hit's
+                 *    gradient): d_T / d_rgb = |state at the prone point - state where the extended walk ends|. */
+                double tn_final = 1.0, nrgb_total[3] = {0, 0, 0}, term_dT = 0.0, term_drgb[3] = {0, 0, 0};
                 if (flip_budget) {
-                    float Tp = 1.0f;
+                    float Tp = 1.0f, rgbp[3] = {0, 0, 0}, T_mark = 0.0f, rgb_mark[3] = {0, 0, 0};
+                    double tn = 1.0;
+                    int marked = 0, dead = 0;
                     for (uint32_t kk = beg; kk < end; ++kk) {
                         const uint32_t id = sorted_ids[kk];
                         if (id == INVALID_IDX) break;
@@ -1041,13 +1102,35 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                         int prone = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu) < flip_bound;
                         if (h.resp > prm->min_kernel_density)
                             prone |= fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu) < flip_bound;
-                        if (prone) taint += h.alpha / (1.0f - h.alpha);
+                        if (prone && !dead) taint += h.alpha / (1.0f - h.alpha);
                         if ((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold)) {
+                            const float wp = h.alpha * Tp;
+                            for (int c = 0; c < 3; ++c) {
+                                const float fv = feat[3 * (size_t)id + c];
+                                const float fc = fv > 0.0f ? fv : 0.0f;
+                                rgbp[c] += wp * fc;
+                                if (!dead) nrgb_total[c] += (double)wp * fc * ((double)nu + tn);
+                            }
                             Tp *= (1.0f - h.alpha);
-                            if (Tp < prm->min_transmittance) break;
+                            tn += (double)h.alpha * nu / (1.0 - (double)h.alpha) + 1.0;
+                            if (!dead) tn_final = tn;
+                            if (!marked && fabs((double)Tp - prm->min_transmittance) / (prm->min_transmittance * 5.9604645e-08 * tn) < flip_bound) {
+                                marked = 1; T_mark = Tp;
+                                for (int c = 0; c < 3; ++c) rgb_mark[c] = rgbp[c];
+                            }
+                            if (Tp < prm->min_transmittance) {
+                                if (!marked) break;
+                                dead = 1;                                   /* walk on for the alternative ending */
+                                if (Tp < 0.25f * prm->min_transmittance) break;
+                            }
                         }
                     }
+                    if (marked) {
+                        term_dT = fabs((double)T_mark - (double)Tp);
+                        for (int c = 0; c < 3; ++c) term_drgb[c] = fabs((double)rgb_mark[c] - (double)rgbp[c]);
+                    }
                 }
+                double nrgb_run[3] = {0, 0, 0}, tn_run = 1.0;   /* the chain noise up to and including the current entry */
                 float T = 1.0f, rgb_run[3] = {0, 0, 0};
                 /* flip budget: once the running transmittance has come within flip_bound noise widths of min_transmittance the
                  * ray may end one entry earlier or later in another evaluation: from there on every entry's contribution is
@@ -1163,6 +1246,33 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                         if (term_prone) prone = 1;
                         const double share = prone ? 1.0 : 4.0 * (double)taint;
                         const double noise = (accept && !ghost) ? 5.9604645e-08 * ((double)nu + 8.0 * cond) : 0.0;
+                        /* (round 4, found with the two-evaluation experiment of tests/test_cpu_oracle.py) the reference's residual
+                         * form carries an ABSOLUTE fp32 error that does not shrink with the transmittance: the final transmittance
+                         * is recovered as 1 - alpha_out (alpha_out is rounded near 1: eps absolute, i.e. eps / T_final relative once
+                         * a ray is opaque) and the colour behind a hit as (rgb_final - rgb_run) / T' (two O(1) numbers rounded to
+                         * eps, divided by a T' down to 1e-4).  G moves by eps x R, R = (|dL/dalpha| + sum_c (|rgb_final_c| +
+                         * |rgb_run_c|) |dL/drgb_c|) / (1 - alpha), whatever T is, while the hit's contribution is proportional to
+                         * T: deep entries of opaque rays (T ~ 1e-3 .. 1e-4) differ between two fp32 evaluations by up to a few
+                         * per cent of their (tiny) rows.  Every geometric row is linear in G: the row moves by |row| / |G| x eps R. */
+                        const double R_abs = ((double)fabsf(T_grad) + ((double)fabsf(rgb_final[0]) + fabs((double)run_after[0])) * fabs((double)rgb_g[0]) +
+                                              ((double)fabsf(rgb_final[1]) + fabs((double)run_after[1])) * fabs((double)rgb_g[1]) +
+                                              ((double)fabsf(rgb_final[2]) + fabs((double)run_after[2])) * fabs((double)rgb_g[2])) / (1.0 - (double)h.alpha);
+                        double noise_abs = (accept && !ghost && G != 0.0f) ? 5.9604645e-08 * 2.0 * R_abs / fabs((double)G) : 0.0;
+                        double flip_term = 0.0;
+                        if (accept && !ghost && G != 0.0f) {
+                            /* chain noise of this hit's G, in eps units: its T (tn_run before this hit), the final T behind the
+                             * density term, the colour still to come behind the hit */
+                            double dG = fabs((double)ga_hit) * tn_run + fabs((double)ga_dns) * tn_final;
+                            for (int c = 0; c < 3; ++c) {
+                                const double later = nrgb_total[c] - nrgb_run[c] - (double)w * f[c] * ((double)nu + tn_run);
+                                dG += fabs((double)rgb_g[c]) * ((double)T * f[c] * tn_run + (later > 0.0 ? later : 0.0) / (1.0 - (double)h.alpha));
+                            }
+                            noise_abs += 5.9604645e-08 * dG / fabs((double)G);
+                            /* termination flip: the finals this hit's residuals are built from may be those of the other ending */
+                            const double dGt = ((double)fabsf(T_grad) * term_dT + fabs((double)rgb_g[0]) * term_drgb[0] +
+                                                fabs((double)rgb_g[1]) * term_drgb[1] + fabs((double)rgb_g[2]) * term_drgb[2]) / (1.0 - (double)h.alpha);
+                            flip_term = dGt / fabs((double)G);
+                        }
                         const double nb[5] = {sqrt(add[0] * add[0] + add[1] * add[1] + add[2] * add[2]), fabs(add[3]),
                                               sqrt(add[4] * add[4] + add[5] * add[5] + add[6] * add[6] + add[7] * add[7]),
                                               sqrt(add[8] * add[8] + add[9] * add[9] + add[10] * add[10]),
@@ -1175,11 +1285,16 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
 #pragma omp atomic
                                 flip_budget[10 * (size_t)id + c] += sh * nb[c];
                             }
+                            if (flip_term > 0.0 && c != 4 && !prone) {
+#pragma omp atomic
+                                flip_budget[10 * (size_t)id + c] += flip_term * nb[c];
+                            }
                             if (noise > 0.0) {
                                 /* positions / rotation / scale: the ray's offset from the Gaussian in units of its size, gro, of
                                  * magnitude gn (1e4 for a sub-pixel Gaussian a few units away), enters through its component
                                  * perpendicular to the ray, of magnitude d ~ 1: a cancellation that leaves eps x gn there */
-                                const double nz_ = (c == 0 || c == 2 || c == 3) ? noise + 5.9604645e-08 * 8.0 * (double)gn : noise;
+                                double nz_ = (c == 0 || c == 2 || c == 3) ? noise + 5.9604645e-08 * 8.0 * (double)gn : noise;
+                                if (c != 4) nz_ += noise_abs;   /* the colour row w x dL/drgb does not go through G */
 #pragma omp atomic
                                 flip_budget[10 * (size_t)id + 5 + c] += nz_ * nb[c];
                             }
@@ -1198,6 +1313,10 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                         }
                     }
                     for (int c = 0; c < 3; ++c) rgb_run[c] = run_after[c];
+                    if (flip_budget) {
+                        for (int c = 0; c < 3; ++c) nrgb_run[c] += (double)w * f[c] * ((double)nu + tn_run);
+                        tn_run += (double)h.alpha * nu / (1.0 - (double)h.alpha) + 1.0;
+                    }
                     T = Tn;
                     if (flip_budget) {
                         t_noise += h.alpha * nu / (1.0f - h.alpha) + 1.0f;   /* as in render_impl */

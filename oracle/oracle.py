@@ -56,6 +56,24 @@ def lib():
     return _LIB
 
 
+class variant:
+    """`with oracle.variant(1): ...` — everything inside evaluates the per-(ray, Gaussian) formulas of the compositing passes in the
+    second fp32 form (gut_oracle.c: eval_hit_fused: FMA, pre-scaled rows, one reciprocal, exp2).  Projection and binning are
+    unaffected (they carry the bit-exact contract).  Tests only: the measured basis of the GPU tolerances."""
+
+    def __init__(self, v):
+        self.v = int(v)
+
+    def __enter__(self):
+        self.prev = int(lib().oracle_get_variant())
+        lib().oracle_set_variant(C.c_int(self.v))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_variant(C.c_int(self.prev))
+        return False
+
+
 def default_params():
     p = OracleParams()
     lib().oracle_default_params(C.byref(p))

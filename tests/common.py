@@ -68,15 +68,18 @@ def rel_l2(a, b):
 
 # A colour difference above the fp32 tolerance is only acceptable where the oracle itself says a hit/no-hit (or early
 # termination) decision along that ray sat within this many fp32-noise widths of its threshold (oracle_render_margins):
-FLIP_MARGIN_BOUND = 6.0   # (4.0 until round 3: a pixel with margin 5.2 was seen to flip on a densified lego-like scene — the noise model is an estimate)
+FLIP_MARGIN_BOUND = 6.0   # = K_BAND x 2.4; two CPU evaluations flip at margins up to 1.9 (derivation at the end of this file)
+COLOUR_TOL = 2e-4         # flat colour tolerance of pixels without a flip-prone decision: two CPU evaluations differ by up to 8.7e-5 there
 
 
-def check_colour_outliers(rgba_gpu, hits_gpu, ref, margins, tol=2e-4, bound=FLIP_MARGIN_BOUND, label="", max_prone=0.05):
-    """Earns the "threshold flip" allowance instead of asserting it: every pixel whose colour differs from the oracle by
-    more than `tol`, or whose hit count differs, must be flip-prone (decision margin < bound); every pixel that is not
-    flip-prone must be within `tol` and have the oracle's hit count.  Returns a small report (fractions, worst margin)."""
+def check_colour_outliers(rgba_gpu, hits_gpu, ref, margins, tol=COLOUR_TOL, bound=FLIP_MARGIN_BOUND, label="", max_prone=0.05, dist_gpu=None):
+    """Earns the "threshold flip" allowance instead of asserting it: every pixel whose colour (and, when given, hit distance)
+    differs from the oracle by more than `tol`, or whose hit count differs, must be flip-prone (decision margin < bound); every
+    pixel that is not flip-prone must be within `tol` and have the oracle's hit count.  Returns a small report (fractions, worst margin)."""
     H, W = ref["rgba"].shape[:2]
     diff = np.abs(np.asarray(rgba_gpu).reshape(H, W, 4) - ref["rgba"]).max(-1)
+    if dist_gpu is not None:     # the integrated hit distance, relative to the frame's largest (it is a length, not a colour)
+        diff = np.maximum(diff, np.abs(np.asarray(dist_gpu).reshape(H, W) - ref["dist"].reshape(H, W)) / max(1.0, float(np.abs(ref["dist"]).max())))
     hdiff = np.asarray(hits_gpu).reshape(H, W) != ref["hits"].reshape(H, W)
     m = margins.min(-1)
     prone = m < bound
@@ -144,9 +147,10 @@ def check_gradient_rows(got, ref, label, budget=None, noise=None, rel_tol=ROW_RE
     assert rep["rel_p999"] <= p999, rep
     if budget is not None:
         assert rep["block_rel_l2_without_rows_needing_budget"] <= block_tol, rep
-        # the flip budget is an estimate (first-order in the flipped hit's alpha, contributions evaluated in the oracle's own
-        # state): a handful of rows may exceed it, by a bounded factor; a systematic error would exceed it on thousands
-        assert rep["rows_over_full_bound"] <= max(3, 5e-5 * rep["rows_nonzero"]) and rep["worst_row_vs_full_bound"] <= 10.0, rep
+        # no escape clause (round 4): the model bounds the measured two-evaluation band of the CPU oracle on every row with
+        # K_BAND to spare (tests/test_cpu_oracle.py::test_two_fp32_evaluations_measure_the_tolerance_model); a row beyond it
+        # means a missing term in the model or a wrong kernel
+        assert rep["rows_over_full_bound"] == 0 and rep["worst_row_vs_full_bound"] <= 1.0, rep
         assert rep["rows_needing_budget"] <= 0.02 * max(1, rep["rows_nonzero"]), rep    # the allowance stays the exception
     return rep
 
@@ -197,3 +201,59 @@ def fisheye_max_angle_edge_case(ulps_above=0):
     view = make_view("fisheye", W, H, np.eye(4, dtype=np.float32), distortion=dict(FISHEYE_DIST, max_angle=float(theta)))
     assert np.float32(view["oracle_cam"]["max_angle"]) == theta
     return sc, view, float(theta)
+
+
+def densified_like_scene(n=20000, seed=5):
+    """A CPU-sized stand-in for what clone / split / training leave behind (tests/test_gpu_densify.py trains a real one on the GPU):
+    a lego-like scene with 30 % of the Gaussians cloned in place, 20 % split into two children drawn inside the parent (scales / 1.6,
+    gs.py:117-160) and opacities pushed up — coincident and nested Gaussians, many opaque rays whose deep entries carry tiny
+    gradients.  Used by the two-evaluation tolerance experiment of tests/test_cpu_oracle.py."""
+    rng = np.random.default_rng(seed)
+    sc = scenes.scene_lego_like(n, seed)
+    clone = rng.random(n) < 0.3
+    split = (~clone) & (rng.random(n) < 0.25)
+    parts = [{k: v[~split] for k, v in sc.items()}, {k: v[clone] for k, v in sc.items()}]
+    par = {k: v[split] for k, v in sc.items()}
+    q = par["rotation"].astype(np.float64)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                  2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    for _ in range(2):
+        child = {k: v.copy() for k, v in par.items()}
+        off = np.einsum("nij,nj->ni", R, par["scale"] * rng.normal(size=par["scale"].shape))
+        child["positions"] = (par["positions"] + off).astype(np.float32)
+        child["scale"] = (par["scale"] / 1.6).astype(np.float32)
+        parts.append(child)
+    out = {k: np.concatenate([p[k] for p in parts]) for k in sc}
+    logit = np.log(out["density"] / (1 - out["density"])) + 2.0
+    out["density"] = (1 / (1 + np.exp(-logit))).astype(np.float32).clip(0, 0.999)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The tolerance model's constants and where they come from (round 4; they do not move: a failing GPU test means a term is missing
+# from the model or a kernel is wrong, not that a constant is too small).
+#
+# oracle/gut_oracle.c evaluates the per-(ray, Gaussian) formulas of the compositing passes in THREE equally valid fp32 forms:
+# variant 0 (the reference's operation order, no contraction, libm expf), variant 1 (what the HIP kernels do: rows of diag(1/s) R^T
+# rounded once, FMAs, |u x o|^2 / |u|^2 with one reciprocal, exp2 of the pre-scaled argument) and variant 2 (variant 1 with the
+# reciprocal / reciprocal-square-root / exp2 results moved by -1 / 0 / +1 ulp, the hardware instructions' specified accuracy).
+# tests/test_cpu_oracle.py::test_two_fp32_evaluations_measure_the_tolerance_model MEASURES |variant 0 - variant v| per pixel and
+# per gradient row on five scenes (toy pinhole, distorted fisheye, big dense splats, 60 k lego-like at 400 x 400, 33 k
+# densified-like) and asserts that the model below, with every constant divided by K_BAND, bounds that band on EVERY pixel and
+# EVERY row, no exceptions:
+#     measured                                                     asserted on the CPU           GPU bound (x K_BAND)
+#     largest decision margin at which two evaluations flip: 1.9   <= FLIP_MARGIN_BOUND / K_BAND  FLIP_MARGIN_BOUND = 6
+#     largest |row difference| / noise(row), rows without budget:  <= ROW_NOISE / K_BAND          ROW_NOISE = 6
+#       1.46 (density), 0.4 .. 1.2 on the geometry blocks
+#     largest |row difference| / (full bound), all rows: 0.31      <= 1 / K_BAND                  ROW_FLIP = 3, ROW_REL, ROW_ABS
+#     largest colour difference of a pixel without a flip-prone    <= COLOUR_TOL / 2              COLOUR_TOL = 2e-4
+#       decision: 8.7e-5
+# The noise model itself was completed with this experiment (gut_oracle.c: render_bwd_impl): it showed rows of two CPU evaluations
+# apart by 73 x the round-3 estimate — deep entries of opaque rays, whose G inherits an ABSOLUTE error from the residual form
+# (T_final = 1 - alpha_out, (rgb_final - rgb_run) / T'), the noise of every alpha in front of them (transmittance chain), and, on
+# rays whose termination is flip-prone, the other ending's finals.  Those are the three terms added in round 4.
+# K_BAND = 2.5 is the one factor between "two CPU evaluations" and "the GPU": the GPU adds fp32 (instead of double) sums over
+# the pixels of a wave and float atomics across waves on top of what variant 2 models.
+K_BAND = 2.5

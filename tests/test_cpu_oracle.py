@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import FISHEYE_DIST, cams, fisheye_max_angle_edge_case, make_view, pose, scenes
+from tests.common import (COLOUR_TOL, FISHEYE_DIST, FLIP_MARGIN_BOUND, GRAD_BLOCKS, K_BAND, ROW_ABS, ROW_FLIP, ROW_FLIP_BOUND, ROW_NOISE, ROW_REL, cams,
+                          densified_like_scene, fisheye_max_angle_edge_case, make_view, pose, scenes)
 
 oracle = importlib.import_module("oracle.oracle")
 prt = importlib.import_module("oracle.per_ray_torch")
@@ -341,3 +342,81 @@ def test_tile_rules_against_an_independent_float64_restatement(kind, W, H):
     lost = fp["in_box"].numpy() & ~kept_t & (exact < thr)
     print(f"[tile rule {kind} {W}x{H}] kept {int(kept_t.sum())} of {int(fp['in_box'].numpy().sum())} boxed pairs; "
           f"{int(lost.sum())} culled although the footprint reaches the tile (the reference's one-point rule)")
+
+
+def _big_splats():
+    sc = scenes.scene_c1(400, 7)
+    sc["scale"] = (sc["scale"] * 4.0).astype(np.float32)
+    sc["density"] = np.clip(sc["density"] * 1.5, 0, 0.999).astype(np.float32)
+    return sc
+
+
+BAND_SCENES = {
+    "c1_pinhole_128": (lambda: scenes.scene_c1(1000, 0), "pinhole", 128, 128, lambda: cams.look_at_c2w((0, 0, -4), (0, 0, 0)), dict(fx=128)),
+    "fisheye_distorted": (lambda: scenes.scene_c1(900, 12), "fisheye", 144, 96, lambda: cams.look_at_c2w((0.1, 0.0, -1.5), (0, 0, 0.5)),
+                          dict(distortion=FISHEYE_DIST)),
+    "dense_big_splats": (_big_splats, "pinhole", 64, 64, lambda: cams.look_at_c2w((0, 0, -3), (0, 0, 0)), dict(fx=64)),
+    "lego_like_60k_400": (lambda: scenes.scene_lego_like(60000, 1), "pinhole_list", 400, 400, lambda: cams.orbit_c2w(4.0, 30, 20), dict(fx=555.0)),
+    "densified_like_30k_320": (lambda: densified_like_scene(20000, 5), "pinhole", 320, 320, lambda: cams.orbit_c2w(3.6, -40, 25), dict(fx=420.0)),
+}
+
+
+@pytest.mark.parametrize("name", list(BAND_SCENES))
+def test_two_fp32_evaluations_measure_the_tolerance_model(name):
+    """The measured basis of the GPU tolerances (tests/common.py, "The tolerance model's constants"): the oracle's compositing
+    passes evaluated in a second and a third equally valid fp32 form (oracle.variant(1): the HIP kernels' own form — FMAs,
+    pre-scaled rows, one reciprocal, exp2; variant(2): the same with 1-ulp reciprocal / rsqrt / exp2, the hardware's accuracy)
+    against the reference-order form.  |variant 0 - variant v| IS an fp32 band of these formulas on this scene; the model the GPU
+    tests use — decision margins for pixels, noise + flip budget for gradient rows — must bound it on EVERY pixel and EVERY row
+    with every constant divided by K_BAND.  No escape clause: nothing is allowed to exceed the model here."""
+    mk, kind, W, H, c2w, kw = BAND_SCENES[name]
+    sc = mk()
+    view = make_view(kind, W, H, c2w(), **kw)
+    cam = view["oracle_cam"]
+    d12, sph = scenes.pack_density(sc), sc["features"]
+    rng = np.random.default_rng(11)
+    rg = rng.normal(size=(H, W, 4)).astype(np.float32)
+    dg = (0.1 * rng.normal(size=(H, W, 1))).astype(np.float32)
+    A = oracle.forward(cam, W, H, d12, sph, view["ro"], view["rd"])
+    margins = oracle.render_margins(cam, A).min(-1)
+    gA, sA, _, budget = oracle.backward(cam, A, rg, dg, flip_bound=ROW_FLIP_BOUND)
+    report = {}
+    for v in (1, 2):
+        with oracle.variant(v):
+            B = oracle.forward(cam, W, H, d12, sph, view["ro"], view["rd"])
+            gB, sB, _ = oracle.backward(cam, B, rg, dg)
+        # the binning is not part of the experiment: identical lists
+        assert np.array_equal(A["sorted_ids"], B["sorted_ids"]) and np.array_equal(A["proj_pos"], B["proj_pos"])
+        # pixels: whatever differs beyond the colour tolerance, or in its hit count, sits within FLIP_MARGIN_BOUND / K_BAND noise
+        # widths of a threshold by the oracle's own margin estimate
+        diff = np.abs(A["rgba"] - B["rgba"]).max(-1)
+        out = (diff > COLOUR_TOL) | (A["hits"] != B["hits"])[..., 0]
+        worst_margin = float(margins[out].max()) if out.any() else 0.0
+        assert worst_margin <= FLIP_MARGIN_BOUND / K_BAND, (name, v, worst_margin)
+        worst_calm_pixel = float(diff[margins >= FLIP_MARGIN_BOUND / K_BAND].max())
+        assert worst_calm_pixel <= COLOUR_TOL / 2.0, (name, v, worst_calm_pixel)    # the flat colour tolerance: measured 8.7e-5 of 2e-4
+        rep = dict(pixel_outliers=int(out.sum()), worst_flip_margin=round(worst_margin, 2), worst_calm_pixel=worst_calm_pixel)
+        # gradient rows
+        for j, (block, sl) in enumerate(GRAD_BLOCKS):
+            a, b = gA[:, sl], gB[:, sl]
+            nr, err = np.linalg.norm(a, axis=1), np.linalg.norm(a - b, axis=1)
+            scale = float(np.quantile(nr[nr > 0], 0.99))
+            noise, flip = budget[:, 5 + j], budget[:, j]
+            calm = (flip == 0) & (nr > 0)
+            # rows no flip-prone decision touches: the fp32 noise estimate alone (no relative or absolute floor) bounds the band
+            r_noise = float((err[calm] / np.maximum(noise[calm], 1e-300)).max())
+            assert r_noise <= ROW_NOISE / K_BAND, (name, v, block, r_noise)
+            full = ROW_REL * nr + ROW_ABS * scale + ROW_NOISE * noise + ROW_FLIP * flip
+            r_full = float((err / np.maximum(full, 1e-300)).max())
+            assert r_full <= 1.0 / K_BAND, (name, v, block, r_full)
+            rep[block] = (round(r_noise, 3), round(r_full, 3))
+        # the SH rows: Y(dir) (x) dL/dRGB, budget columns 4 / 9 with the basis norm (tests/common.check_gradients_per_row)
+        y = math.sqrt(16 / (4 * math.pi))
+        nr, err = np.linalg.norm(sA, axis=1), np.linalg.norm(sA - sB, axis=1)
+        scale = float(np.quantile(nr[nr > 0], 0.99))
+        full = ROW_REL * nr + ROW_ABS * scale + ROW_NOISE * budget[:, 9] * y + ROW_FLIP * budget[:, 4] * y
+        r_full = float((err / np.maximum(full, 1e-300)).max())
+        assert r_full <= 1.0 / K_BAND, (name, v, "sh", r_full)
+        rep["sh"] = round(r_full, 3)
+        report[v] = rep
+    print(f"[band {name}] {report}")

