@@ -65,7 +65,8 @@ class GutStats(C.Structure):
 
 
 class GutLazyMoments(C.Structure):
-    _fields_ = [("d_wave_step", C.c_void_p), ("d_pow_beta1", C.c_void_p), ("d_pow_beta2", C.c_void_p), ("table_len", C.c_uint32)]
+    _fields_ = [("d_wave_step", C.c_void_p), ("d_pow_beta1", C.c_void_p), ("d_pow_beta2", C.c_void_p), ("table_len", C.c_uint32),
+                ("d_overrun", C.c_void_p)]
 
 
 EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_trace_bwd", "gut_collect_times",

@@ -66,6 +66,7 @@ struct LazyMoments {
     const float* pow2 = nullptr;
     uint32_t len = 0;
     uint32_t t = 0;     // the optimiser step being applied (1-based)
+    uint32_t* overrun = nullptr;   // GutLazyMoments.d_overrun
 };
 
 // ---- launch wrappers implemented in the .hip files -------------------------------------------------

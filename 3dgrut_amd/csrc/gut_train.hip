@@ -202,7 +202,8 @@ __device__ __forceinline__ float2 missed_decay(const LazyMoments& lz, uint32_t w
     if (!lz.wave_step) return make_float2(1.0f, 1.0f);
     const uint32_t seen = lz.wave_step[wave];
     const uint32_t d = lz.t > seen ? lz.t - seen - 1u : 0u;
-    const uint32_t k = d < lz.len ? d : lz.len - 1u;   // (the trainer brings every wave up to date long before the table ends)
+    const uint32_t k = d < lz.len ? d : lz.len - 1u;   // (the trainer brings every wave up to date long before the table ends ...
+    if (d >= lz.len && lz.overrun) *lz.overrun = 1u;   //  ... and is told when a wave was not: its decay below is wrong)
     return make_float2(lz.pow1[k], lz.pow2[k]);
 }
 
@@ -885,6 +886,7 @@ __global__ __launch_bounds__(kBlock) void k_sync_moments(uint32_t n, float4* __r
     if (seen >= lz.t) return;
     const uint32_t d = lz.t - seen;
     const uint32_t k = d < lz.len ? d : lz.len - 1u;
+    if (d >= lz.len && lz.overrun && lane == 0) *lz.overrun = 1u;
     const float f1 = lz.pow1[k], f2 = lz.pow2[k];
     const uint32_t rows_here = min(64u, n - wave_first);
     for (uint32_t q = lane; q < rows_here * 3u; q += 64u) {
@@ -907,6 +909,7 @@ gut::LazyMoments gut_make_lazy(const GutLazyMoments* lazy, uint32_t step) {
     gut::LazyMoments lz;
     if (lazy && lazy->d_wave_step && lazy->d_pow_beta1 && lazy->d_pow_beta2 && lazy->table_len >= 2 && step >= 1) {
         lz.wave_step = lazy->d_wave_step; lz.pow1 = lazy->d_pow_beta1; lz.pow2 = lazy->d_pow_beta2; lz.len = lazy->table_len; lz.t = step;
+        lz.overrun = lazy->d_overrun;
     }
     return lz;
 }

@@ -165,7 +165,8 @@ class NativeTrainStep:
         self._pow1 = torch.as_tensor((float(np.float32(betas[0])) ** k).astype(np.float32), device=dev)
         self._pow2 = torch.as_tensor((float(np.float32(betas[1])) ** k).astype(np.float32), device=dev)
         self.wave_step = None
-        self.step_id = 0
+        self._lazy_overrun = torch.zeros(1, dtype=torch.int32, device=dev)   # GutLazyMoments.d_overrun, checked in sync_moments()
+        self._step_id = 0
         self.fused_loss = bool(fused_loss)
         self.fuse_epilogue = bool(fuse_epilogue)
         # one view, fused epilogue: the Adam step of the 64-row waves that cannot receive a gradient from the view (no tile, or
@@ -274,11 +275,59 @@ class NativeTrainStep:
         """GutLazyMoments for the optimiser entry points, or None."""
         if not self.lazy_moments or self.wave_step is None:
             return None
-        return _capi.GutLazyMoments(self.wave_step.data_ptr(), self._pow1.data_ptr(), self._pow2.data_ptr(), self.LAZY_TABLE)
+        return _capi.GutLazyMoments(self.wave_step.data_ptr(), self._pow1.data_ptr(), self._pow2.data_ptr(), self.LAZY_TABLE,
+                                    self._lazy_overrun.data_ptr())
+
+    # The step counter and the per-wave `wave_step` of the lazy moment decay belong together: a wave's stored moments are current up
+    # to wave_step[w] and every reader multiplies them by beta^(step - wave_step[w]).  So the counter cannot simply be assigned
+    # (ADVICE r3: st.step_id = k on a resumed trainer left wave_step at 0 and the first step multiplied every moment by beta^1023):
+    # assigning it goes through set_step(), which brings the stored moments up to date at the OLD count first and then re-bases
+    # every wave on the new one; _end_of_step advances the private counter.
+    @property
+    def step_id(self):
+        return self._step_id
+
+    @step_id.setter
+    def step_id(self, value):
+        self.set_step(value)
+
+    def set_step(self, step):
+        """Set the number of optimiser steps applied so far (resume, tests).  The moments keep their values: they are brought up to
+        date at the current count, then every wave is marked current at the new one."""
+        step = int(step)
+        if step < 0:
+            raise ValueError("step must be >= 0")
+        if step != self._step_id:
+            self.sync_moments()
+            self._step_id = step
+            if self.wave_step is not None:
+                self.wave_step.fill_(step)
+
+    def state_dict(self):
+        """Optimiser state for a checkpoint: the step count and the four moment tensors, CURRENT (sync_moments() first — with the
+        lazy decay the stored tensors alone are stale), as clones.  Parameters are the model's (model.raw / model.features)."""
+        self.sync_moments()
+        return dict(step=int(self._step_id), exp_avg_raw=self.m12.clone(), exp_avg_sq_raw=self.v12.clone(),
+                    exp_avg_features=self.m48.clone(), exp_avg_sq_features=self.v48.clone(), lr_raw=self.lr12.copy())
+
+    def load_state_dict(self, state):
+        """Inverse of state_dict() on a trainer of the same size: moments copied in, every wave marked current at the saved step."""
+        n = self.model.num_gaussians
+        for key, dst in (("exp_avg_raw", self.m12), ("exp_avg_sq_raw", self.v12), ("exp_avg_features", self.m48), ("exp_avg_sq_features", self.v48)):
+            src = state[key]
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"load_state_dict: {key} has shape {tuple(src.shape)}, the trainer holds {n} Gaussians ({tuple(dst.shape)})")
+            dst.copy_(src)
+        if "lr_raw" in state:
+            self.lr12[:] = np.asarray(state["lr_raw"], np.float32)
+        self._step_id = int(state["step"])
+        if self.wave_step is not None:
+            self.wave_step.fill_(self._step_id)
 
     def sync_moments(self):
         """Bring every stored Adam moment up to the last step applied (gut_sync_moments).  Call before reading m12 / v12 / m48 /
-        v48, and before anything that moves rows between 64-row waves (reorder and the strategy's row surgery do)."""
+        v48, and before anything that moves rows between 64-row waves (reorder and the strategy's row surgery do).  Raises if any
+        kernel since the last call met a wave whose moments had missed more steps than the beta^k tables hold (its decay was wrong)."""
         lz = self._lazy()
         if lz is None or self.model.num_gaussians == 0 or not self.model.raw.is_cuda:
             return
@@ -288,6 +337,11 @@ class NativeTrainStep:
                                             self.m48.data_ptr(), self.v48.data_ptr(), C.byref(lz), int(self.step_id))
         if rc:
             raise RuntimeError(f"[3dgut] sync_moments failed ({rc})")
+        if int(self._lazy_overrun.item()):   # (a blocking read, on a path that runs every LAZY_TABLE / 2 steps and on row surgery)
+            self._lazy_overrun.zero_()
+            raise RuntimeError(f"[3dgut] lazy moment decay: a wave's stored Adam moments had missed {self.LAZY_TABLE} or more steps "
+                               "(wave_step does not belong to step_id: use set_step() / load_state_dict() to resume, never a bare "
+                               "assignment of wave_step or of the moments)")
 
     def reorder(self, perm: torch.Tensor):
         """Apply a row permutation to the parameters and the optimiser state (new row i = old row perm[i])."""
@@ -467,7 +521,7 @@ class NativeTrainStep:
     def step(self, batch):
         try:
             return self._step(batch)
-        except BaseException:
+        except Exception as err:
             # The side-stream optimiser pass may already be running for this iteration (it is queued right behind the forward):
             # finish the step for every other row with a zero gradient instead of leaving the parameters half advanced and the
             # handle refusing the next forward (gut_optimize_finish_without_gradient); then let the error through.
@@ -475,14 +529,25 @@ class NativeTrainStep:
                 self._early_queued = False
                 try:
                     self.raster.finish_optimizer_step_without_gradient()
-                    self._act_key = None
-                    self.step_id += 1   # the iteration WAS applied: every row took its step, with a zero gradient
-                except Exception:
-                    pass
+                except Exception as finish_err:
+                    # the handle is half applied and cannot be repaired from here (a HIP error, most likely): say both
+                    raise RuntimeError(f"[3dgut] the optimiser step begun on the side stream could not be finished after "
+                                       f"{type(err).__name__}: {err}; the trainer's state is not usable: {finish_err}") from err
+                self._act_key = None
+                self._probe_evs = None
+                # the iteration WAS applied — every row took its step, with a zero gradient — so it goes through the same
+                # bookkeeping as any other (learning-rate / SH-degree schedule, sync cadence of the lazy moments, step count)
+                self._end_of_step(None)
             raise
 
     def _step(self, batch):
         m = self.model
+        if self.world_size > 1 and self.replica_check_every and not getattr(self, "_replicas_checked_at_start", False):
+            # BEFORE the first update of this trainer (`step_id % every == 0` alone fires after it): ranks that were built from
+            # different scenes, seeds or checkpoints are caught while nothing has been applied yet
+            self._replicas_checked_at_start = True
+            assert_replicas_identical([self.model.raw, self.model.features, self.m12, self.v12, self.m48, self.v48], self.world_size,
+                                      what=f"before the first step (step counter {self.step_id})")
         evs = [] if self.phase_timing else None
         self._mark(evs)
         one_pass = self.fused and self.world_size <= 1 and not self.force_exchange and self.fuse_epilogue \
@@ -729,8 +794,8 @@ class NativeTrainStep:
             lr, deg = self.schedule.after_optimizer_step(self.step_id)
             self.lr12[0:3] = lr         # passed by value to the optimiser kernels of the next step
             self.model.n_active_features = deg
-        self.step_id += 1
-        if self.lazy_moments and self.step_id % (self.LAZY_TABLE // 2) == 0:
+        self._step_id += 1
+        if self.lazy_moments and self._step_id % (self.LAZY_TABLE // 2) == 0:
             self.sync_moments()   # long before any wave's missed steps run off the end of the beta^k tables
 
     def render(self, batch, train=False):

@@ -79,6 +79,71 @@ def scene_outdoor_like(n=6_000_000, seed=2, extent=12.0, n_blobs=64, ground_frac
     return {k: val[perm] for k, val in out.items()}
 
 
+def _quat_from_normal(rng, nrm):
+    """Unit quaternions (wxyz) whose rotation maps the local z axis onto `nrm` [n,3] (unit), with a random spin about it."""
+    n = nrm.shape[0]
+    z = np.array([0.0, 0.0, 1.0])
+    ax = np.cross(np.broadcast_to(z, nrm.shape), nrm)
+    s = np.linalg.norm(ax, axis=1, keepdims=True)
+    c = nrm[:, 2:3]
+    ax = np.where(s > 1e-9, ax / np.maximum(s, 1e-9), np.array([1.0, 0.0, 0.0]))
+    half = 0.5 * np.arctan2(s, c)
+    q1 = np.concatenate([np.cos(half), ax * np.sin(half)], 1)               # z -> nrm
+    spin = rng.uniform(0, 2 * math.pi, size=(n, 1)) * 0.5
+    q0 = np.concatenate([np.cos(spin), np.zeros((n, 2)), np.sin(spin)], 1)  # about local z first
+    w1, x1, y1, z1 = q1.T
+    w0, x0, y0, z0 = q0.T
+    q = np.stack([w1 * w0 - x1 * x0 - y1 * y0 - z1 * z0, w1 * x0 + x1 * w0 + y1 * z0 - z1 * y0,
+                  w1 * y0 - x1 * z0 + y1 * w0 + z1 * x0, w1 * z0 + x1 * y0 - y1 * x0 + z1 * w0], 1)
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def scene_surface_like(n=6_000_000, seed=6, extent=12.0, n_objects=48, ground_frac=0.45, far_frac=0.2, scale_mu=math.log(0.02),
+                       scale_sigma=0.6, flatness=0.12, opacity_logit_mean=-1.6, opacity_logit_std=1.3, far_scale=6.0, thickness=0.01):
+    """A SURFACE-like stand-in for a trained outdoor scene: every Gaussian sits on a 2-D shell — a ground
+    disc, the skins of `n_objects` ellipsoids around the centre, a far dome — as a flat disc aligned with the surface (normal scale
+    = flatness x tangential scale), nothing fills a volume, so that nothing is buried inside opaque blobs: a ray meets one to three
+    semi-transparent layers and walks most of its tile's list before it saturates.  Opacities follow a trained scene's histogram
+    (most low, a tail near one).  Tuned (tools/scene_stats.py) to E/M >= 0.5, walked rows >= 0.6 V, M/V 6 - 10 from the bench's
+    cameras — the other end of the range from scene_outdoor_like, whose Gaussians mostly sit inside blobs (E/M = 0.12)."""
+    rng = np.random.default_rng(seed)
+    n_ground = int(n * ground_frac)
+    n_far = int(n * far_frac)
+    n_obj = n - n_ground - n_far
+    # objects: ellipsoid skins
+    centers = rng.normal(0.0, 1.3, size=(n_objects, 3)) * np.array([1.0, 0.3, 1.0])
+    radii = rng.uniform(0.15, 0.9, size=(n_objects, 3))
+    area = (radii[:, 0] * radii[:, 1] + radii[:, 1] * radii[:, 2] + radii[:, 0] * radii[:, 2])
+    which = rng.choice(n_objects, size=n_obj, p=area / area.sum())
+    u = rng.normal(size=(n_obj, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    obj = centers[which] + u * radii[which] * (1.0 + rng.normal(0, thickness, size=(n_obj, 1)))
+    obj_n = u / radii[which]
+    obj_n /= np.linalg.norm(obj_n, axis=1, keepdims=True)
+    # ground disc at y = +1 (down is +y), normal -y
+    r = extent * np.sqrt(rng.uniform(0.0, 1.0, size=n_ground))
+    a = rng.uniform(0, 2 * math.pi, size=n_ground)
+    ground = np.stack([r * np.cos(a), 1.0 + rng.normal(0, thickness, size=n_ground), r * np.sin(a)], axis=1)
+    ground_n = np.tile(np.array([[0.0, -1.0, 0.0]]), (n_ground, 1)) + rng.normal(0, 0.05, size=(n_ground, 3))
+    ground_n /= np.linalg.norm(ground_n, axis=1, keepdims=True)
+    # far dome
+    v = rng.normal(size=(n_far, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[:, 1] = -np.abs(v[:, 1])
+    far = v * (2.0 * extent) * (1.0 + rng.normal(0, thickness, size=(n_far, 1)))
+    far_n = -v
+    pos = np.concatenate([obj, ground, far], axis=0)
+    nrm = np.concatenate([obj_n, ground_n, far_n], axis=0)
+    ls_t = rng.normal(scale_mu, scale_sigma, size=(n, 1))
+    ls = np.concatenate([ls_t + rng.normal(0, 0.25, size=(n, 2)), ls_t + math.log(flatness) + rng.normal(0, 0.25, size=(n, 1))], axis=1)
+    ls[n_obj + n_ground:] += math.log(far_scale)
+    ls = np.clip(ls, math.log(3e-4), math.log(3.0))
+    out = _finish(rng, pos, ls, n, opacity_logit_std=opacity_logit_std, opacity_logit_mean=opacity_logit_mean)
+    out["rotation"] = _quat_from_normal(rng, nrm).astype(np.float32)
+    perm = rng.permutation(n)
+    return {k: val[perm] for k, val in out.items()}
+
+
 def pack_density(scene):
     """[N,12] particle_density as packed by _Autograd.forward (tracer.py:176-178)."""
     n = scene["positions"].shape[0]

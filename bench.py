@@ -475,7 +475,8 @@ def main():
                          "with tiles the forward walked nothing of (library default 100)")
     ap.add_argument("--no-placement-tuning", action="store_true",
                     help="keep the trainer state where the allocator first put it (default: NativeTrainStep.tune_placement re-places the three "
-                         "[N,48] tensors, each at most twice, while the optimiser's no-op pass gets > 3 %% faster)")
+                         "[N,48] tensors one at a time, round robin, up to --placement-attempts fresh allocations each, and stops at the first "
+                         "move that makes the optimiser's no-op pass > 5 %% faster)")
     ap.add_argument("--placement-attempts", type=int, default=4, help="fresh allocations tried per [N,48] tensor by tune_placement (it stops at the first that is faster)")
     ap.add_argument("--ply", default=None,
                     help="render / train THIS scene instead of the synthetic stand-in: a 3DGS-compatible PLY (threedgrut/model/model.py:"
@@ -490,7 +491,8 @@ def main():
                     help="write both Adam moments of every row every step (default: waves that cannot receive a gradient read their moments, "
                          "bring them up to date in registers and do not write them back; gut_hip.h: GutLazyMoments)")
     ap.add_argument("--force-overlap-optimizer", action="store_true",
-                    help="always use the side-stream optimiser pass (default: the trainer times both forms in steps 1-4 and keeps the faster)")
+                    help="always use the side-stream optimiser pass (default: the trainer alternates the two forms over steps 2-9 and keeps the one "
+                         "whose best sample is faster)")
     ap.add_argument("--densification-statistics", action="store_true",
                     help="native trainer: attach strategy.GSStrategy, whose per-view position-gradient statistics run between backward "
                          "and optimiser in every step (the densification phase of a reference run; the number is NOT the headline)")

@@ -33,7 +33,8 @@ extern "C" {
  * gut_optimize_finish_without_gradient, gut_scatter_gradient_records_dev, gut_trace_fields / gut_trace_bwd_fields;
  * 4: gut_trace_model_fields / gut_trace_bwd_model_fields, gut_position_gradient_statistics, gut_set_position_gradient_statistics,
  * gut_mcmc_perturb; 5: behaviour, not layout — GUT_OPT_SORTED_REFERENCE_BACKWARD defaults to 1, the reference's own form of the
- * sorted variant's backward; the UT sigma-point spread is rounded from double like the reference's build script does). */
+ * sorted variant's backward; the UT sigma-point spread is rounded from double like the reference's build script does;
+ * GutLazyMoments.d_overrun). */
 #define GUT_ABI_VERSION 5
 
 typedef struct gut_context* gut_handle;
@@ -320,6 +321,10 @@ typedef struct GutLazyMoments {
     const float* d_pow_beta1;    /* [table_len] */
     const float* d_pow_beta2;    /* [table_len] */
     uint32_t table_len;
+    uint32_t* d_overrun;         /* may be NULL; one word, caller-zeroed: set to 1 by any kernel that met a wave whose stored moments
+                                    had missed table_len or more steps (its decay factor does not exist in the tables: the caller
+                                    resumed with a wave_step that does not belong to its step counter, or never called
+                                    gut_sync_moments).  The caller checks it where it synchronises anyway (ABI 5) */
 } GutLazyMoments;
 int gut_sync_moments(void* stream, uint32_t num_particles, float* d_raw_m, float* d_raw_v, float* d_sh_m, float* d_sh_v,
                      const GutLazyMoments* lazy, uint32_t step /* the last optimiser step applied */);

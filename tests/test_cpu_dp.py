@@ -55,12 +55,17 @@ def test_single_rank_is_a_no_op():
 COUNTS = [(5, 40, 0), (0, 0, 0), (300, 7, 12), (20, 280, 3), (1, 2, 3)]   # ragged, all empty, beyond the carried capacity, within it
 
 
-def _records_worker(rank, world, port, out_dir):
+# the node's world size: one rank never has a record (its view looks away from the scene), counts ragged over two orders of magnitude,
+# one step in which a single rank overflows the carried capacity, one in which every rank is empty
+COUNTS8 = [(5, 40, 0, 17, 3, 0, 29, 1), (0, 0, 0, 0, 0, 0, 0, 0), (12, 7, 0, 300, 9, 2, 44, 8), (250, 280, 0, 3, 120, 64, 65, 1), (1, 2, 0, 4, 5, 6, 7, 8)]
+
+
+def _records_worker(rank, world, port, out_dir, table=None, torn_rank=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ex = dp.RecordExchange(world, min_capacity=8, granule=8)
     outs = []
-    for step, counts in enumerate(COUNTS):
+    for step, counts in enumerate(COUNTS if table is None else table):
         g = torch.Generator().manual_seed(1000 * step + rank)
         rec = torch.randn((300, 16), generator=g)          # capacity = "number of Gaussians"; rows beyond the count are stale
         cap_before = ex.capacity
@@ -78,7 +83,7 @@ def _records_worker(rank, world, port, out_dir):
     same = [torch.arange(12.0).reshape(3, 4), torch.ones(5)]
     dp.assert_replicas_identical(same, world)
     diff = [t.clone() for t in same]
-    if rank == 1:
+    if rank == torn_rank:
         diff[1][2] = 1.0000001
     try:
         dp.assert_replicas_identical(diff, world, what="test")
@@ -109,6 +114,29 @@ def test_three_rank_sparse_record_exchange(tmp_path):
     chk = [torch.load(os.path.join(tmp_path, f"chk{k}.pt")) for k in range(world)]
     assert all(c["raised"] for c in chk)
     assert chk[0]["info"]["backend"] == "gloo" and chk[0]["info"]["world_size_seen"] == world
+
+
+def test_eight_rank_sparse_record_exchange(tmp_path):
+    """The exchange at the node's world size (no 8-GPU node is available to the builder, so this is what the
+    N = 8 bench run's host logic has been through): eight gloo ranks, one of them never has a record, ragged counts, a step in which
+    ONE rank overflows the capacity carried from earlier steps (every rank must take the tail path), an all-empty step; every rank
+    ends every step with every rank's records, bit-identical and in rank order; the replica self-check trips on every rank when the
+    LAST rank's copy differs in one bit."""
+    world = 8
+    mp.spawn(_records_worker, args=(world, _free_port(), str(tmp_path), COUNTS8, world - 1), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rec{k}.pt")) for k in range(world)]
+    for step, counts in enumerate(COUNTS8):
+        for k in range(world):
+            assert r[k][step]["counts"] == list(counts)
+            for src in range(world):
+                assert r[k][step]["rows"][src].shape == (counts[src], 16)
+                assert torch.equal(r[k][step]["rows"][src], r[src][step]["mine"])
+            assert r[k][step]["cap"] == r[0][step]["cap"] and r[k][step]["overflowed"] == r[0][step]["overflowed"]   # same path on every rank
+    s = r[0]
+    assert [x["overflowed"] for x in s] == [False, False, True, False, False]
+    assert s[0]["cap"] == 64 and s[2]["cap"] == 64 and s[3]["cap"] == 300 and s[4]["bytes"] == world * 300 * 64
+    chk = [torch.load(os.path.join(tmp_path, f"chk{k}.pt")) for k in range(world)]
+    assert all(c["raised"] for c in chk) and chk[0]["info"]["world_size_seen"] == world
 
 
 def test_single_rank_record_exchange():

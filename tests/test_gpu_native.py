@@ -721,6 +721,68 @@ def test_lazy_moments_over_more_steps_than_the_decay_tables_hold():
     assert torch.allclose(eager.model.features[never], lazy.model.features[never], rtol=1e-6, atol=1e-7)
 
 
+def test_checkpoint_resume_beyond_the_decay_tables():
+    """the public moment tensors are stale under the lazy decay and `wave_step` belongs to the step counter.
+    state_dict() syncs before it exports; load_state_dict() / set_step() re-base every wave; a trainer resumed at step 1500 (beyond
+    the 1024-entry beta^k tables) continues exactly like the one that never stopped and like the trainer that writes its moments
+    every step; a resume that bypasses them (moments copied, wave_step left behind) is REPORTED instead of silently multiplying
+    every moment by beta^1023."""
+    sc = scenes.scene_c1(20000, 33)
+    W, H = 96, 72
+    gt = torch.rand((1, H, W, 3), generator=torch.Generator().manual_seed(9)).to(DEV)
+    views = [make_view("pinhole", W, H, cams.look_at_c2w((0.05 * k, 0.0, 0.02 * k), d), fx=90.0)
+             for k, d in enumerate([(1, 0, 0), (-1, 0.2, 0), (0, 1, 0.1)])]
+    batches = []
+    for v in views:
+        b = to_batch(v, DEV); b.T_to_world = b.T_to_world.cpu(); b.rgb_gt = gt
+        batches.append(b)
+
+    def make(lazy):
+        model = native.NativeGaussianModel(sc, device=DEV, spatial_order=True)
+        st = native.NativeTrainStep(model, gut.Tracer({"render": {}}), scene_extent=1.0, overlap_optimizer=True, lazy_moments=lazy)
+        g = torch.Generator(device=DEV).manual_seed(7)
+        for m_, v_ in ((st.m12, st.v12), (st.m48, st.v48)):
+            m_.normal_(0.0, 1e-4, generator=g)
+            v_.fill_(1e-6)
+        return st
+
+    eager, lazy = make(False), make(True)
+    for st in (eager, lazy):
+        st.set_step(1500)                       # a run that is 1500 steps old (the moments keep their values)
+        assert st.step_id == 1500 and (st.wave_step is None or int(st.wave_step.min()) == 1500)
+    for k in range(6):
+        for st in (eager, lazy):
+            st.step(batches[k % 3])
+    assert int(lazy.wave_step.min()) < lazy.step_id            # some waves ARE behind: the stored moments are stale ...
+    stale = lazy.m48.clone()
+    sd = lazy.state_dict()                                     # ... and the checkpoint holds current ones
+    assert sd["step"] == 1506 and not torch.equal(stale, sd["exp_avg_features"])
+    assert torch.allclose(sd["exp_avg_sq_features"], eager.v48, rtol=2e-6, atol=0.0)
+    assert torch.allclose(sd["exp_avg_features"], eager.m48, rtol=1e-5, atol=1e-12)
+    # resume into a fresh trainer
+    resumed = make(True)
+    resumed.model.raw.copy_(lazy.model.raw); resumed.model.features.copy_(lazy.model.features)
+    resumed.load_state_dict(sd)
+    assert resumed.step_id == 1506 and int(resumed.wave_step.min()) == 1506
+    for k in range(6, 12):
+        for st in (eager, lazy, resumed):
+            st.step(batches[k % 3])
+    for st in (lazy, resumed):
+        st.sync_moments()
+    for name in ("m12", "v12", "m48", "v48"):
+        assert torch.equal(getattr(lazy, name), getattr(resumed, name)), name          # the resumed run IS the uninterrupted one
+    assert torch.equal(lazy.model.raw, resumed.model.raw) and torch.equal(lazy.model.features, resumed.model.features)
+    assert torch.allclose(eager.model.features, lazy.model.features, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(eager.v48, lazy.v48, rtol=1e-5, atol=0.0)
+    # the unsafe resume: moments copied into a fresh trainer, the private counter forced, wave_step left at 0
+    bad = make(True)
+    bad.model.raw.copy_(lazy.model.raw); bad.model.features.copy_(lazy.model.features)
+    bad._step_id = 1512
+    bad.step(batches[0])
+    with pytest.raises(RuntimeError, match="missed 1024 or more steps"):
+        bad.sync_moments()
+
+
 def test_spatial_storage_order_is_transparent():
     """NativeGaussianModel(spatial_order=True) only permutes the rows: same image, and after two train steps the parameters
     are those of the scene-order model, row for row through `permutation` (up to the float-atomic noise of the backward);

@@ -9,8 +9,9 @@ W, H, fx = 1237, 822, 1040.0
 ro, rd = cams.pinhole_rays(W, H, fx, fx)
 K = cams.pinhole_intrinsics_dict(W, H, fx, fx)
 variants = json.loads(sys.argv[1]) if len(sys.argv) > 1 else [dict()]
+fn = sys.argv[2] if len(sys.argv) > 2 else "scene_outdoor_like"     # e.g. scene_surface_like
 for kw in variants:
-    sc = scenes.scene_outdoor_like(n=6_000_000, seed=2, **kw)
+    sc = getattr(scenes, fn)(**dict(dict(n=6_000_000, seed=2), **kw))
     model = model_mod.GaussianModel(sc, device=dev)
     tr = gut.Tracer({"render": {"enable_kernel_timings": True}})
     for az in (7.0, 97.0):
@@ -22,6 +23,11 @@ for kw in variants:
                 out = tr.render(model, b)
         st = tr.tracer_wrapper.stats(); kt = tr.tracer_wrapper.kernel_times()
         op = out["pred_opacity"].mean().item(); hc = out["hits_count"].mean().item()
-        print(json.dumps(dict(kw=kw, az=az, V=st["num_visible"], M=st["num_intersections"], Ef=st["traversed_fwd"],
+        # Gaussians the forward walked (the rows a backward can give a gradient to): distinct ids among the ordered prefixes
+        oid = tr.tracer_wrapper.debug_buffer("ordered_ids")
+        walked = int(torch.unique(oid[oid != -1]).numel())     # int32 view of the u32 list, padding 0xFFFFFFFF
+        print(json.dumps(dict(kw=kw, az=az, V=st["num_visible"], M=st["num_intersections"], Ef=st["traversed_fwd"], walked_gaussians=walked,
+                              E_over_M=round(st["traversed_fwd"] / max(1, st["num_intersections"]), 3), walked_over_V=round(walked / max(1, st["num_visible"]), 3),
+                              M_over_V=round(st["num_intersections"] / max(1, st["num_visible"]), 2),
                               mean_opacity=round(op, 3), mean_hits=round(hc, 1), ms={k: round(v, 3) for k, v in kt.items() if v >= 0})))
     del model, tr
