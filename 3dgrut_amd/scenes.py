@@ -99,13 +99,19 @@ def _quat_from_normal(rng, nrm):
 
 
 def scene_surface_like(n=6_000_000, seed=6, extent=12.0, n_objects=48, ground_frac=0.45, far_frac=0.2, scale_mu=math.log(0.02),
-                       scale_sigma=0.6, flatness=0.12, opacity_logit_mean=-1.6, opacity_logit_std=1.3, far_scale=6.0, thickness=0.01):
+                       scale_sigma=0.6, flatness=0.12, opacity_logit_mean=-4.5, opacity_logit_std=1.8, far_scale=6.0, thickness=0.01):
     """A SURFACE-like stand-in for a trained outdoor scene: every Gaussian sits on a 2-D shell — a ground
     disc, the skins of `n_objects` ellipsoids around the centre, a far dome — as a flat disc aligned with the surface (normal scale
     = flatness x tangential scale), nothing fills a volume, so that nothing is buried inside opaque blobs: a ray meets one to three
-    semi-transparent layers and walks most of its tile's list before it saturates.  Opacities follow a trained scene's histogram
-    (most low, a tail near one).  Tuned (tools/scene_stats.py) to E/M >= 0.5, walked rows >= 0.6 V, M/V 6 - 10 from the bench's
-    cameras — the other end of the range from scene_outdoor_like, whose Gaussians mostly sit inside blobs (E/M = 0.12)."""
+    semi-transparent layers and walks about half of its tile's list before it saturates.  Opacities: most low, a tail near one
+    (logit N(-4.5, 1.8): median 0.011, 10 % above 0.1, 1.5 % above 0.5).  Measured from the bench's cameras (tools/scene_stats.py on
+    MI355X, round 4, 6 M Gaussians, 1237 x 822): V = 1.83 - 1.86 M, M = 7.1 - 7.5 M (M/V = 3.9 - 4.0), E = 3.0 - 3.6 M, **E/M = 0.41 -
+    0.50**, 0.38 - 0.46 of the visible Gaussians walked, 240 - 260 blended hits per pixel, mean opacity 0.95 - 0.98 — the other end of
+    the range from scene_outdoor_like, whose Gaussians mostly sit inside opaque blobs (E/M = 0.12, 0.1 of V walked).  E/M >= 0.5 AND
+    M/V = 6 - 10 together were not reachable with this geometry: a pixel then lies inside the bounding boxes of V x (footprint area)
+    / P ~ 4000 Gaussians, about 40 % of which hit it, so the list is only half walked if the mean effective alpha per hit is below
+    0.01; measured along that front: M/V = 4.0 -> E/M 0.45, M/V = 5.6 -> 0.24, M/V = 9 -> 0.27 at 600 hits per pixel, M/V = 11 ->
+    0.27 at 700 (gpurun_out/r4/surf*.log)."""
     rng = np.random.default_rng(seed)
     n_ground = int(n * ground_frac)
     n_far = int(n * far_frac)

@@ -769,9 +769,11 @@ def test_checkpoint_resume_beyond_the_decay_tables():
             st.step(batches[k % 3])
     for st in (lazy, resumed):
         st.sync_moments()
+    # the resumed run IS the uninterrupted one, up to the float-atomic order of the two trainers' backward passes
     for name in ("m12", "v12", "m48", "v48"):
-        assert torch.equal(getattr(lazy, name), getattr(resumed, name)), name          # the resumed run IS the uninterrupted one
-    assert torch.equal(lazy.model.raw, resumed.model.raw) and torch.equal(lazy.model.features, resumed.model.features)
+        assert torch.allclose(getattr(lazy, name), getattr(resumed, name), rtol=2e-5, atol=1e-10), name
+    assert torch.allclose(lazy.model.raw, resumed.model.raw, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(lazy.model.features, resumed.model.features, rtol=1e-6, atol=1e-7)
     assert torch.allclose(eager.model.features, lazy.model.features, rtol=1e-5, atol=1e-7)
     assert torch.allclose(eager.v48, lazy.v48, rtol=1e-5, atol=0.0)
     # the unsafe resume: moments copied into a fresh trainer, the private counter forced, wave_step left at 0

@@ -7,6 +7,8 @@ bench.WORKLOADS), HIP path through the C ABI against the CPU oracle on identical
   * bicycle_like_6M_survey_c3                SURVEY 8d C3's literal parameters: M = 32 M intersections; rendered right after a
                                              frame with far fewer, so the forward is queued against too small a capacity and
                                              the overflow redo (gut_trace) is what produces the checked frame
+  * bicycle_like_6M_surface                  the surface-like stand-in (the other end of the headline's bracket): half of every tile's
+                                             list walked, 250 blended hits per pixel, many rays that never saturate
 
 Bars: every integer buffer and every projection float bit-exact; image within 2e-4 except on pixels where the oracle
 itself reports a hit/no-hit decision within FLIP_MARGIN_BOUND noise widths of its threshold (tests/common.py);
@@ -51,7 +53,7 @@ def _frame(workload):
 
 
 @pytest.mark.parametrize("workload", ["lego_like_300k_800x800", "scannetpp_like_fisheye_300k_1752x1168", "garden_like_5M_1297x840",
-                                      "bicycle_like_6M_survey_c3"])
+                                      "bicycle_like_6M_survey_c3", "bicycle_like_6M_surface"])
 def test_workload_against_the_oracle(workload):
     fr = _frame(workload)
     W, H, st, raster = fr["W"], fr["H"], fr["stepper"], fr["tracer"].tracer_wrapper
