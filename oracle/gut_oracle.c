@@ -815,9 +815,36 @@ static void eval_hit(const OracleParams* prm, const float* g, const float rows[3
     h->alpha = a < prm->max_alpha ? a : prm->max_alpha;
 }
 
+/* fp32 noise of a pair's response, in units of eps = 2^-24, for ANY evaluation order of the formula (tests only: decision margins,
+ * flip budgets, row conditioning).  resp = exp(-d2 / 2), d2 = |grd x gro|^2:
+ *   - c = grd x gro is a cancellation: an absolute error delta(grd) |gro| + delta(gro) in each component of a vector of length sqrt(d2);
+ *   - gro = diag(1/s) R (o - mu): R (o - mu) carries eps |o - mu| per component, divided by s_k: delta(gro) <= eps |o - mu| / s_min
+ *     (for an isotropic Gaussian that IS eps |gro|; for a flat disc seen along its plane it is |1/s|_max / |1/s|_eff times more);
+ *   - grd = normalize(diag(1/s) R d): delta(grd) <= eps (1 / s_min) / |diag(1/s) R d|  (1 for an isotropic Gaussian);
+ *   - delta(d2) = 2 sqrt(d2) delta(c), delta(resp) / resp = delta(d2) / 2, plus exp's argument and result rounding (d2 / 2 + 2).
+ * The two anisotropy factors were missing until round 4 (found with the surface-like stand-in, whose flat 8 : 1 discs made two CPU
+ * evaluations differ by up to 9 x the old estimate, gpurun_out/r4/outliers_surface.json); the factor 1/2 keeps the estimate what it
+ * was for isotropic Gaussians (sqrt(d2) |gro|), on which every constant of tests/common.py was measured. */
+static float hit_noise(const Hit* h, const float* s) {
+    const float gn = sqrtf(h->gro[0] * h->gro[0] + h->gro[1] * h->gro[1] + h->gro[2] * h->gro[2]);
+    float is_max = 1.0f / s[0];
+    if (1.0f / s[1] > is_max) is_max = 1.0f / s[1];
+    if (1.0f / s[2] > is_max) is_max = 1.0f / s[2];
+    const float lu = sqrtf(h->grdu[0] * h->grdu[0] + h->grdu[1] * h->grdu[1] + h->grdu[2] * h->grdu[2]);
+    const float lp = sqrtf(h->gposc[0] * h->gposc[0] + h->gposc[1] * h->gposc[1] + h->gposc[2] * h->gposc[2]);
+    float spread = 0.5f * (gn * (lu > 0.0f ? is_max / lu : 1.0f) + lp * is_max);
+    if (!(spread >= gn)) spread = gn;
+    return sqrtf(h->d2) * spread + 0.5f * h->d2 + 2.0f;
+}
+
 /* K6: render — gutRenderer.cuh:83-115, gutKBufferRenderer.cuh:108-170,217-292 (K=0),
  * rayPayload.cuh:110-129.  Also returns per-tile traversal counts (entries fetched before the
  * whole tile terminated) for the roofline statistics E_f. */
+/* tests only: when set, the next render / render_bwd also writes each tile's traversal depth (list entries fetched before every ray
+ * of the tile had ended) there; the totals they return are the sums */
+static uint32_t* g_tile_traversed_out = NULL;
+void oracle_set_tile_traversed_out(uint32_t* p) { g_tile_traversed_out = p; }
+
 static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W, int H,
                    const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir,
@@ -850,12 +877,8 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                     eval_hit(prm, g, rows, &ray, &h);
                     float nu = 0.0f;
                     if (margins) {
-                        /* fp32 noise of the response, in units of eps = 2^-24, for ANY evaluation order of this formula:
-                         * c = grd x gro carries an absolute error ~ eps |gro| per component (cancellation), so
-                         * delta(d2) ~ 2 sqrt(d2) eps |gro| and delta(resp)/resp = delta(d2)/2; plus exp's argument/result
-                         * rounding (d2/2 + 2). */
-                        const float gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
-                        nu = sqrtf(h.d2) * gn + 0.5f * h.d2 + 2.0f;
+                        /* fp32 noise of the response in eps units: hit_noise() */
+                        nu = hit_noise(&h, g + 8);
                         const float eps = 5.9604645e-08f;
                         const float mr = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu);
                         if (mr < m_thr) m_thr = mr;
@@ -898,8 +921,40 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                 if (margins) { margins[2 * pix] = m_thr; margins[2 * pix + 1] = m_trm; }
             }
         traversed_total += deepest;
+        if (g_tile_traversed_out) g_tile_traversed_out[tile] = deepest;
     }
     if (traversed_out) *traversed_out = traversed_total;
+}
+
+/* tests / investigations only: the entries one ray walks, as this evaluation sees them.  out[k] = {id, d2, resp, alpha, nu, accepted,
+ * T after the entry, |gro|} for the k-th listed entry of the ray's tile, until the ray ends or `max_entries` are written; returns
+ * the number written. */
+int oracle_debug_ray(const OracleParams* prm, const OracleCamera* cam, int W, int H, const float* density12,
+                     const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
+                     int px, int py, double* out, int max_entries) {
+    const PoseSet ps = make_pose_set(cam);
+    const int gx = (W + GUT_TILE - 1) / GUT_TILE;
+    const int tile = (py / GUT_TILE) * gx + px / GUT_TILE;
+    const size_t pix = (size_t)py * W + px;
+    Ray ray = make_ray(&ps, ray_ori + 3 * pix, ray_dir + 3 * pix);
+    int n = 0;
+    float T = 1.0f;
+    for (uint32_t k = ranges[2 * tile]; k < ranges[2 * tile + 1] && ray.alive && n < max_entries; ++k) {
+        const uint32_t id = sorted_ids[k];
+        if (id == INVALID_IDX) break;
+        const float* g = density12 + (size_t)id * 12;
+        float rows[3][3];
+        quat_to_rows(g + 4, rows);
+        Hit h;
+        eval_hit(prm, g, rows, &ray, &h);
+        const float gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
+        const float nu = hit_noise(&h, g + 8);
+        const int acc = (h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold);
+        if (acc) { T *= (1.0f - h.alpha); if (T < prm->min_transmittance) ray.alive = 0; }
+        double* o = out + 8 * (size_t)n++;
+        o[0] = id; o[1] = h.d2; o[2] = h.resp; o[3] = h.alpha; o[4] = nu; o[5] = acc; o[6] = T; o[7] = gn;
+    }
+    return n;
 }
 
 void oracle_render(const OracleParams* prm, const OracleCamera* cam, int W, int H,
@@ -1097,8 +1152,7 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                         quat_to_rows(g + 4, rows);
                         Hit h;
                         eval_hit(prm, g, rows, &ray, &h);
-                        const float gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
-                        const float nu = sqrtf(h.d2) * gn + 0.5f * h.d2 + 2.0f, eps = 5.9604645e-08f;
+                        const float nu = hit_noise(&h, g + 8), eps = 5.9604645e-08f;
                         int prone = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu) < flip_bound;
                         if (h.resp > prm->min_kernel_density)
                             prone |= fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu) < flip_bound;
@@ -1153,7 +1207,7 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                     if (flip_budget) {
                         gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
                         const float eps = 5.9604645e-08f;
-                        nu = sqrtf(h.d2) * gn + 0.5f * h.d2 + 2.0f;
+                        nu = hit_noise(&h, g + 8);
                         prone = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu) < flip_bound;
                         if (h.resp > prm->min_kernel_density)
                             prone |= fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu) < flip_bound;
@@ -1334,6 +1388,7 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                 if (k_end - beg > deepest) deepest = k_end - beg;
             }
         traversed_total += deepest;
+        if (g_tile_traversed_out) g_tile_traversed_out[tile] = deepest;
     }
     if (traversed_out) *traversed_out = traversed_total;
 }

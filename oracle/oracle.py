@@ -159,12 +159,28 @@ def forward(cam: dict, W, H, density12, sph48, ray_ori, ray_dir, sh_degree=3, pa
     rgba = np.zeros((H, W, 4), np.float32); dist = np.full((H, W, 1), 1e6, np.float32)
     hits = np.zeros((H, W, 1), np.float32)
     trav = C.c_uint64(0)
+    tile_trav = np.zeros(T, np.uint32)
     if M:  # zero intersections => early return with untouched outputs (gutRenderer.cu:323-325)
+        L.oracle_set_tile_traversed_out(_p(tile_trav))
         L.oracle_render(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), _p(d12), _p(out["feat"]),
                         _p(ro), _p(rd), _p(ranges), _p(sids), _p(rgba), _p(dist), _p(hits), C.byref(trav))
-    out.update(rgba=rgba, dist=dist, hits=hits, traversed_fwd=int(trav.value),
+        L.oracle_set_tile_traversed_out(None)
+    out.update(rgba=rgba, dist=dist, hits=hits, traversed_fwd=int(trav.value), tile_traversed_fwd=tile_trav,
                _inputs=(d12, sph, ro, rd, sh_degree, W, H))
     return out
+
+
+def debug_ray(cam: dict, fwd: dict, px, py, params=None, max_entries=4096):
+    """[n,8] float64: id, d2, response, alpha, noise estimate nu, accepted, T after, |gro| of the entries pixel (px, py) walks."""
+    L = lib()
+    prm = params or default_params()
+    c = make_camera(cam)
+    d12, sph, ro, rd, sh_degree, W, H = fwd["_inputs"]
+    out = np.zeros((max_entries, 8), np.float64)
+    L.oracle_debug_ray.restype = C.c_int
+    n = L.oracle_debug_ray(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), _p(d12), _p(ro), _p(rd), _p(fwd["tile_ranges"]), _p(fwd["sorted_ids"]),
+                           C.c_int(int(px)), C.c_int(int(py)), _p(out), C.c_int(max_entries))
+    return out[:n]
 
 
 def render_margins(cam: dict, fwd: dict, params=None):
@@ -218,6 +234,9 @@ def backward(cam: dict, fwd: dict, rgba_grad, dist_grad, params=None, flip_bound
     sph_g = np.zeros((N, 48), np.float64)
     trav = C.c_uint64(0)
     budget = np.zeros((N, 10), np.float64) if flip_bound is not None else None
+    tile_trav = np.zeros(fwd["tile_ranges"].shape[0], np.uint32)
+    if fwd["M"]:
+        L.oracle_set_tile_traversed_out(_p(tile_trav))
     if fwd["M"] and budget is not None:
         L.oracle_render_bwd_budget(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), _p(d12), _p(fwd["feat"]),
                                    _p(ro), _p(rd), _p(fwd["tile_ranges"]), _p(fwd["sorted_ids"]),
@@ -230,7 +249,9 @@ def backward(cam: dict, fwd: dict, rgba_grad, dist_grad, params=None, flip_bound
     if fwd["M"]:
         L.oracle_project_bwd(C.byref(c), C.c_uint32(N), C.c_int(sh_degree), _p(d12), _p(fwd["tiles_count"]),
                              _p(fwd["feat"]), _p(feat_g), _p(sph_g))
+    L.oracle_set_tile_traversed_out(None)
     fwd["traversed_bwd"] = int(trav.value)
+    fwd["tile_traversed_bwd"] = tile_trav
     if budget is not None:
         return dens_g, sph_g, feat_g, budget
     return dens_g, sph_g, feat_g

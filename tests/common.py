@@ -95,6 +95,26 @@ def check_colour_outliers(rgba_gpu, hits_gpu, ref, margins, tol=COLOUR_TOL, boun
     return rep
 
 
+def check_tile_traversal(got_tiles, ref_tiles, margins, W, H, label="", bound=FLIP_MARGIN_BOUND):
+    """Per-tile traversal depths (list entries fetched before every ray of the tile had ended; their sum is E of the byte model).
+    A tile's depth is where its LAST ray ended, so it moves when one termination (or the hit that causes it) flips between two fp32
+    evaluations: every tile whose depth differs from the oracle's must hold a pixel whose decision margin is below `bound` — the same
+    evidence the colour check asks for.  Opaque scenes agree exactly; scenes whose rays barely saturate differ on a handful of tiles."""
+    got = np.asarray(got_tiles).astype(np.int64).reshape(-1)
+    ref = np.asarray(ref_tiles).astype(np.int64).reshape(-1)
+    assert got.shape == ref.shape
+    bad = np.nonzero(got != ref)[0]
+    gx = (W + 15) // 16
+    m = margins.min(-1)
+    for t in bad:
+        ty, tx = divmod(int(t), gx)
+        tile_m = m[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]
+        assert tile_m.size and float(tile_m.min()) < bound, f"{label}: tile {t} walked {got[t]} entries, the oracle {ref[t]}, and no decision of its rays is near a threshold ({float(tile_m.min()):.1f})"
+    assert bad.size <= max(2, 0.01 * got.size), f"{label}: {bad.size} of {got.size} tiles differ in traversal depth"
+    print(f"[traversal {label}] {bad.size} of {got.size} tiles differ (all flip-prone), total {int(got.sum())} vs {int(ref.sum())}")
+    return int(bad.size)
+
+
 # ---- per-row gradient parity (a global relative L2 over a 6 M-row block hides a few thousand wrong rows) ----
 GRAD_BLOCKS = (("positions", slice(0, 3)), ("density", slice(3, 4)), ("rotation", slice(4, 8)), ("scale", slice(8, 11)))
 # `scale` of a block = the 99th-percentile row norm of the oracle's non-zero rows.  EVERY row must satisfy
@@ -240,20 +260,24 @@ def densified_like_scene(n=20000, seed=5):
 # rounded once, FMAs, |u x o|^2 / |u|^2 with one reciprocal, exp2 of the pre-scaled argument) and variant 2 (variant 1 with the
 # reciprocal / reciprocal-square-root / exp2 results moved by -1 / 0 / +1 ulp, the hardware instructions' specified accuracy).
 # tests/test_cpu_oracle.py::test_two_fp32_evaluations_measure_the_tolerance_model MEASURES |variant 0 - variant v| per pixel and
-# per gradient row on five scenes (toy pinhole, distorted fisheye, big dense splats, 60 k lego-like at 400 x 400, 33 k
-# densified-like) and asserts that the model below, with every constant divided by K_BAND, bounds that band on EVERY pixel and
-# EVERY row, no exceptions:
+# per gradient row on six scenes (toy pinhole, distorted fisheye, big dense splats, 60 k lego-like at 400 x 400, 33 k
+# densified-like, 400 k flat discs of the surface-like stand-in) and asserts that the model below, with every constant divided by
+# K_BAND, bounds that band on EVERY pixel and EVERY row, no exceptions:
 #     measured                                                     asserted on the CPU           GPU bound (x K_BAND)
-#     largest decision margin at which two evaluations flip: 1.9   <= FLIP_MARGIN_BOUND / K_BAND  FLIP_MARGIN_BOUND = 6
+#     largest decision margin at which two evaluations flip: 1.43  <= FLIP_MARGIN_BOUND / K_BAND  FLIP_MARGIN_BOUND = 6
 #     largest |row difference| / noise(row), rows without budget:  <= ROW_NOISE / K_BAND          ROW_NOISE = 6
-#       1.46 (density), 0.4 .. 1.2 on the geometry blocks
-#     largest |row difference| / (full bound), all rows: 0.31      <= 1 / K_BAND                  ROW_FLIP = 3, ROW_REL, ROW_ABS
+#       2.2 (rotation rows of flat discs), 1.0 elsewhere
+#     largest |row difference| / (full bound), all rows: 0.30      <= 1 / K_BAND                  ROW_FLIP = 3, ROW_REL, ROW_ABS
 #     largest colour difference of a pixel without a flip-prone    <= COLOUR_TOL / 2              COLOUR_TOL = 2e-4
 #       decision: 8.7e-5
 # The noise model itself was completed with this experiment (gut_oracle.c: render_bwd_impl): it showed rows of two CPU evaluations
 # apart by 73 x the round-3 estimate — deep entries of opaque rays, whose G inherits an ABSOLUTE error from the residual form
 # (T_final = 1 - alpha_out, (rgb_final - rgb_run) / T'), the noise of every alpha in front of them (transmittance chain), and, on
-# rays whose termination is flip-prone, the other ending's finals.  Those are the three terms added in round 4.
+# rays whose termination is flip-prone, the other ending's finals.  Those are the three terms added in round 4; a fourth followed when
+# the GPU met the surface-like stand-in (two hit-count flips at 6.4 and 11.5 "noise widths"): the response's noise estimate assumed
+# isotropic Gaussians, and for flat 8 : 1 discs the canonical-space direction and origin carry |1/s|_max / |1/s|_effective times
+# more rounding error (hit_noise in gut_oracle.c) — with it those two decisions sit at 1 - 2 widths, and the CPU figures above are
+# the ones measured with it.
 # K_BAND = 2.5 is the one factor between "two CPU evaluations" and "the GPU": the GPU adds fp32 (instead of double) sums over
 # the pixels of a wave and float atomics across waves on top of what variant 2 models.
 K_BAND = 2.5

@@ -358,6 +358,10 @@ BAND_SCENES = {
     "dense_big_splats": (_big_splats, "pinhole", 64, 64, lambda: cams.look_at_c2w((0, 0, -3), (0, 0, 0)), dict(fx=64)),
     "lego_like_60k_400": (lambda: scenes.scene_lego_like(60000, 1), "pinhole_list", 400, 400, lambda: cams.orbit_c2w(4.0, 30, 20), dict(fx=555.0)),
     "densified_like_30k_320": (lambda: densified_like_scene(20000, 5), "pinhole", 320, 320, lambda: cams.orbit_c2w(3.6, -40, 25), dict(fx=420.0)),
+    # flat 8 : 1 discs on shells, mostly faint, seen at grazing angles and from far away (the bench's surface-like stand-in, thinned):
+    # the anisotropy terms of the noise estimate (gut_oracle.c: hit_noise) are what this scene measures
+    "surface_like_400k_384x256": (lambda: scenes.scene_surface_like(400_000, 6, scale_mu=math.log(0.05)), "pinhole", 384, 256,
+                                  lambda: cams.orbit_c2w(4.5, 7.0, 12.0), dict(fx=320.0)),
 }
 
 
