@@ -29,11 +29,34 @@
 #include "gut_internal.h"
 #include "gut_render_common.h"
 
+#include <type_traits>
+
 namespace gut {
 
+// Staged entry of the two unsorted compositors: the thirteen floats every (pixel, entry) test needs sit in the first 13 dwords read
+// per entry (three ds_read_b128 + one ds_read_b32); the scales — needed by a HIT only (hit distance) — follow as one aligned
+// ds_read_b96, the colour and the id as before.  Against FwdEntry's rows [m_i.xyz | s_i] this frees three VGPRs in each of the two
+// register sets of the software pipeline (round 4: k_render no longer spills inside its loop).
+struct PackEntry {     // 80 bytes
+    float4 q0;         // oc = M (sensor_pos - mean), density
+    float4 q1;         // m00 m01 m02 m10
+    float4 q2;         // m11 m12 m20 m21
+    float4 q3;         // s.x s.y s.z m22
+    float4 feat_id;    // max(rgb, 0), particle id (bit pattern)
+};
+__device__ __forceinline__ PackEntry pack_entry(const FwdEntry& e) {
+    PackEntry p;
+    p.q0 = e.mu_sigma;
+    p.q1 = make_float4(e.m0.x, e.m0.y, e.m0.z, e.m1.x);
+    p.q2 = make_float4(e.m1.y, e.m1.z, e.m2.x, e.m2.y);
+    p.q3 = make_float4(e.m0.w, e.m1.w, e.m2.w, e.m2.z);
+    p.feat_id = e.feat_id;
+    return p;
+}
+
 // stage[j] for a list index held in a VGPR: 24-bit multiply (full rate) instead of the quarter-rate 32-bit one
-__device__ __forceinline__ const FwdEntry& stage_at(const FwdEntry* stage, uint32_t j) {
-    return *reinterpret_cast<const FwdEntry*>(reinterpret_cast<const char*>(stage) + __umul24(j, (uint32_t)sizeof(FwdEntry)));
+__device__ __forceinline__ const PackEntry& stage_at(const PackEntry* stage, uint32_t j) {
+    return *reinterpret_cast<const PackEntry*>(reinterpret_cast<const char*>(stage) + __umul24(j, (uint32_t)sizeof(PackEntry)));
 }
 
 template <int kCtrl, int kRowMask>
@@ -74,7 +97,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                                                      float* __restrict__ hits, uint32_t* __restrict__ tile_traversed,
                                                      const uint2* __restrict__ tile_keys, uint32_t* __restrict__ ordered_ids,
                                                      uint32_t* __restrict__ tile_ordered) {
-    __shared__ FwdEntry stage[kBlock];
+    __shared__ PackEntry stage[kBlock];
     __shared__ uint32_t s_deepest, s_first_invalid;
     __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (8x8 blocks) can hit it at all
     __shared__ uint16_t s_list[kBlock / 64][kBlock];  // per wave: the staged entries it has to evaluate (index), in list order
@@ -103,15 +126,22 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
 
     const uint2 range = ranges[tile];
     const uint32_t total = range.y - range.x;
-    bool alive = ray.valid;
-    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dsum = 0.f;
-    uint32_t nhits = 0, consumed = 0;
+    // The ray's "alive" flag lives in the SIGN of its transmittance (alive <=> T > 0; a ray that ends keeps -T): one v_cmp per entry
+    // serves the wave's "anyone left?" branch and the lane mask of the evaluation, where a separate boolean cost the loop five moves
+    // and two more compares per entry (ISA of round 3).  T > 0 while alive: alpha <= max_alpha < 1 and T >= min_transmittance before
+    // every multiplication.
+    float T = ray.valid ? 1.0f : -1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dsum = 0.f;
+    uint32_t nhits = 0;
     bool have_lo = false;           // kLazy: the last list entry ordered so far (block-uniform)
     uint32_t lo_d = 0, lo_p = 0, batch_n = 0, batch_used = 0;
 
     uint32_t base = 0;  // list entries staged so far (kept after the loop: the ordered prefix handed to the backward)
+    // The walk, instantiated twice on the block-uniform `centred` (every camera of the reference has centred rays): the centred form
+    // carries neither the M e product nor the registers of e nor the per-entry branch and copies that merging the two forms cost.
+    auto walk = [&](auto centred_tag) __attribute__((always_inline)) {
+    constexpr bool kCentred = decltype(centred_tag)::value;
     for (; base < total; base += kBlock) {
-        if (!__syncthreads_or(alive ? 1 : 0)) break;  // whole tile terminated (gutKBufferRenderer.cuh:234-236)
+        if (!__syncthreads_or(T > 0.0f ? 1 : 0)) break;  // whole tile terminated (gutKBufferRenderer.cuh:234-236)
         {
             const uint32_t k = range.x + base + tid;
             uint32_t id = kInvalid;
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
                 strips = strip_mask(s_planes, v, c, a, r, s);
             }
-            stage[tid] = e;
+            stage[tid] = pack_entry(e);
             s_mask[tid] = strips;
             if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
         }
@@ -163,18 +193,18 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
         // entries of this chunk that are real particles (padding ids end the list for everyone, gutKBufferRenderer.cuh:256-259)
         const uint32_t cnt = min(min((uint32_t)kBlock, total - base), s_first_invalid);
         // software pipeline: the parameters of entry j+1 are fetched from LDS while entry j is evaluated
-        auto entry = [&](const float4& cs, const float4& c0, const float4& c1, const float4& c2, const uint32_t j)
+        auto entry = [&](const float4& cs, const float4& q1, const float4& q2, const float m22, const uint32_t j)
                          __attribute__((always_inline)) {
-            if (alive) {
+            if (T > 0.0f) {
                 float o0 = cs.x, o1 = cs.y, o2 = cs.z;
-                if (!centred) {
-                    o0 += c0.x * ray.ex + c0.y * ray.ey + c0.z * ray.ez;
-                    o1 += c1.x * ray.ex + c1.y * ray.ey + c1.z * ray.ez;
-                    o2 += c2.x * ray.ex + c2.y * ray.ey + c2.z * ray.ez;
+                if (!kCentred) {
+                    o0 += q1.x * ray.ex + q1.y * ray.ey + q1.z * ray.ez;
+                    o1 += q1.w * ray.ex + q2.x * ray.ey + q2.y * ray.ez;
+                    o2 += q2.z * ray.ex + q2.w * ray.ey + m22 * ray.ez;
                 }
-                const float u0 = c0.x * ray.dx + c0.y * ray.dy + c0.z * ray.dz;
-                const float u1 = c1.x * ray.dx + c1.y * ray.dy + c1.z * ray.dz;
-                const float u2 = c2.x * ray.dx + c2.y * ray.dy + c2.z * ray.dz;
+                const float u0 = q1.x * ray.dx + q1.y * ray.dy + q1.z * ray.dz;
+                const float u1 = q1.w * ray.dx + q2.x * ray.dy + q2.y * ray.dz;
+                const float u2 = q2.z * ray.dx + q2.w * ray.dy + m22 * ray.dz;
                 const float x0 = u1 * o2 - u2 * o1, x1 = u2 * o0 - u0 * o2, x2 = u0 * o1 - u1 * o0;
                 const float l2 = u0 * u0 + u1 * u1 + u2 * u2;
                 const float il2 = fast_rcp(l2);
@@ -185,7 +215,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                     if ((resp > c.min_response) && (alpha > c.alpha_threshold)) {
                         // hitT = | s * grd * (grd . -gro) |
                         const float proj = -(u0 * o0 + u1 * o1 + u2 * o2) * il2;  // (grd.-gro)/|u|
-                        const float h0 = c0.w * u0 * proj, h1 = c1.w * u1 * proj, h2 = c2.w * u2 * proj;
+                        const float4 sc = stage_at(stage, j).q3;                   // the scales: read by hits only
+                        const float h0 = sc.x * u0 * proj, h1 = sc.y * u1 * proj, h2 = sc.z * u2 * proj;
                         const float hit_t = fast_sqrt(h0 * h0 + h1 * h1 + h2 * h2);
                         if ((hit_t > ray.tmin) && (hit_t < ray.tmax)) {
                             const float w = alpha * T;
@@ -199,8 +230,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                                 nhits++;
                             }
                             if (T < c.min_transmittance) {
-                                alive = false;
-                                consumed = base + j + 1;  // list position at which this ray terminated
+                                T = -T;                                   // the ray ends here
+                                atomicMax(&s_deepest, base + j + 1);      // list position at which it ended (once per ray)
                             }
                         }
                     }
@@ -227,31 +258,36 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             uint32_t ja = list[0], jb = list[1];  // list positions i and i+1 (garbage beyond nw is never evaluated)
-            float4 a0 = stage_at(stage, ja).mu_sigma, a1 = stage_at(stage, ja).m0, a2 = stage_at(stage, ja).m1, a3 = stage_at(stage, ja).m2;
-            float4 b0, b1, b2, b3;
+            float4 a0 = stage_at(stage, ja).q0, a1 = stage_at(stage, ja).q1, a2 = stage_at(stage, ja).q2;
+            float a3 = stage_at(stage, ja).q3.w;
+            float4 b0, b1, b2;
+            float b3;
             uint32_t i = 0;
             while (i < nw) {
-                if (__ballot(alive) == 0ull) break;  // wave-uniform
-                b0 = stage_at(stage, jb).mu_sigma; b1 = stage_at(stage, jb).m0; b2 = stage_at(stage, jb).m1; b3 = stage_at(stage, jb).m2;
+                if (__ballot(T > 0.0f) == 0ull) break;  // wave-uniform
+                b0 = stage_at(stage, jb).q0; b1 = stage_at(stage, jb).q1; b2 = stage_at(stage, jb).q2; b3 = stage_at(stage, jb).q3.w;
                 const uint32_t jc = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(a0, a1, a2, a3, ja);
                 if (++i >= nw) break;
-                if (__ballot(alive) == 0ull) break;
-                a0 = stage_at(stage, jc).mu_sigma; a1 = stage_at(stage, jc).m0; a2 = stage_at(stage, jc).m1; a3 = stage_at(stage, jc).m2;
+                if (__ballot(T > 0.0f) == 0ull) break;
+                a0 = stage_at(stage, jc).q0; a1 = stage_at(stage, jc).q1; a2 = stage_at(stage, jc).q2; a3 = stage_at(stage, jc).q3.w;
                 const uint32_t jd = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(b0, b1, b2, b3, jb);
                 ++i;
                 ja = jc;
                 jb = jd;
             }
-            if (alive) consumed = base + cnt;  // walked the whole chunk (skipped entries included) and is still alive
+            // a ray still alive has walked the whole chunk (skipped entries included)
+            if (__ballot(T > 0.0f) != 0ull && lane == 0) atomicMax(&s_deepest, base + cnt);
         }
-        if (cnt < min((uint32_t)kBlock, total - base)) alive = false;  // list ended at a padding entry
+        if (cnt < min((uint32_t)kBlock, total - base)) T = -fabsf(T);  // list ended at a padding entry
     }
+    };
+    if (centred) walk(std::true_type{}); else walk(std::false_type{});
 
     if (inside) {
         if (ray.valid) {
-            rgba[pix] = make_float4(cr, cg, cb, 1.0f - T);
+            rgba[pix] = make_float4(cr, cg, cb, 1.0f - fabsf(T));
             dist[pix] = dsum;
             hits[pix] = (float)nhits;
         } else {  // initial values of the reference's output tensors (splatRaster.cpp:196-198)
@@ -260,8 +296,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
             hits[pix] = 0.0f;
         }
     }
-    // traversal statistics (E_f of the roofline model): deepest list position any pixel of the tile consumed
-    atomicMax(&s_deepest, consumed);
+    // traversal statistics (E_f of the roofline model): deepest list position any pixel of the tile consumed (s_deepest)
     __syncthreads();
     if (tid == 0) {
         tile_traversed[tile] = s_deepest;
@@ -383,7 +418,7 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
                                                            const uint32_t* __restrict__ tile_order,
                                                            const uint32_t* __restrict__ tile_walked) {
     constexpr int W = AccLayout<kDistGrad>::kW;
-    __shared__ FwdEntry stage[kBlock];
+    __shared__ PackEntry stage[kBlock];
     __shared__ float acc[kBlock * W];
     __shared__ uint32_t s_deepest, s_first_invalid;
     __shared__ uint32_t s_mask[kBlock];              // see k_render
@@ -441,6 +476,9 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
     bool alive = ray.valid && usable;
     float T = 1.0f, rr = 0.f, rg = 0.f, rb = 0.f;  // running transmittance / radiance
     uint32_t consumed = 0;
+    // the walk, instantiated on the block-uniform `centred` (see k_render)
+    auto walk = [&](auto centred_tag) __attribute__((always_inline)) {
+    constexpr bool kCentred = decltype(centred_tag)::value;
     for (uint32_t base = 0; base < total; base += kBlock) {
         if (!__syncthreads_or(alive ? 1 : 0)) break;
         {
@@ -468,7 +506,7 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
                 strips = strip_mask(s_planes, v, c, a, r, sc);
             }
-            stage[tid] = e;
+            stage[tid] = pack_entry(e);
             s_mask[tid] = strips;
             if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
         }
@@ -477,17 +515,18 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
         const uint32_t cnt_all = min((uint32_t)kBlock, total - base);
         const uint32_t cnt = min(cnt_all, s_first_invalid);  // padding ids end the list for everyone
         // one list entry for this wave's 64 pixels
-        auto entry = [&](const float4& ms, const float4& m0, const float4& m1, const float4& m2, const uint32_t j)
+        // (p1, p2, p3: PackEntry.q1 / q2 / q3; q3 = scales + m22; only the hit-distance instantiation looks at the scales)
+        auto entry = [&](const float4& ms, const float4& p1, const float4& p2, const float4& p3, const uint32_t j)
                          __attribute__((always_inline)) {
             float o0 = ms.x, o1 = ms.y, o2 = ms.z;
-            if (!centred) {
-                o0 += m0.x * rex + m0.y * rey + m0.z * rez;
-                o1 += m1.x * rex + m1.y * rey + m1.z * rez;
-                o2 += m2.x * rex + m2.y * rey + m2.z * rez;
+            if (!kCentred) {
+                o0 += p1.x * rex + p1.y * rey + p1.z * rez;
+                o1 += p1.w * rex + p2.x * rey + p2.y * rez;
+                o2 += p2.z * rex + p2.w * rey + p3.w * rez;
             }
-            const float u0 = m0.x * rdx + m0.y * rdy + m0.z * rdz;
-            const float u1 = m1.x * rdx + m1.y * rdy + m1.z * rdz;
-            const float u2 = m2.x * rdx + m2.y * rdy + m2.z * rdz;
+            const float u0 = p1.x * rdx + p1.y * rdy + p1.z * rdz;
+            const float u1 = p1.w * rdx + p2.x * rdy + p2.y * rdz;
+            const float u2 = p2.z * rdx + p2.w * rdy + p3.w * rdz;
             const float c0 = u1 * o2 - u2 * o1, c1 = u2 * o0 - u0 * o2, c2 = u0 * o1 - u1 * o0;
             const float l2 = u0 * u0 + u1 * u1 + u2 * u2;
             const float il2 = fast_rcp(l2);
@@ -518,7 +557,7 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
                 il = fast_rsq(l2);
                 d0 = u0 * il; d1 = u1 * il; d2n = u2 * il;
                 const float proj = -(d0 * o0 + d1 * o1 + d2n * o2);
-                const float s0 = m0.w * d0 * proj, s1 = m1.w * d1 * proj, s2 = m2.w * d2n * proj;  // grds
+                const float s0 = p3.x * d0 * proj, s1 = p3.y * d1 * proj, s2 = p3.z * d2n * proj;  // grds
                 const float gsq = s0 * s0 + s1 * s1 + s2 * s2;
                 const float gdist = fast_sqrt(gsq);
                 ga_hit = gdist * T * gd;
@@ -547,7 +586,7 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             if (!kDistGrad) {
                 // m = (ray_o - mu) - t d = (e - t d) + (sensor_pos - mu); the second, per-entry constant part is
                 // added in the epilogue as H (x) (sensor_pos - mu)
-                const float n0 = rex - t * rdx, n1 = rey - t * rdy, n2 = rez - t * rdz;
+                const float n0 = (kCentred ? 0.0f : rex) - t * rdx, n1 = (kCentred ? 0.0f : rey) - t * rdy, n2 = (kCentred ? 0.0f : rez) - t * rdz;
                 g[0] = h0 * n0; g[1] = h0 * n1; g[2] = h0 * n2;
                 g[3] = h1 * n0; g[4] = h1 * n1; g[5] = h1 * n2;
                 g[6] = h2 * n0; g[7] = h2 * n1; g[8] = h2 * n2;
@@ -555,19 +594,20 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
                 float v0 = -t * h0, v1 = -t * h1, v2 = -t * h2;  // dL/du from the response term
                 // reference's diagonal hit-distance terms: d/d(gro) and d/d(grd) (gaussianParticles.cuh:559-567)
                 const float x0 = d0 * o0, x1 = d1 * o1, x2 = d2n * o2;
-                h0 += -m0.w * d0 * d0 * k0;
-                h1 += -m1.w * d1 * d1 * k1;
-                h2 += -m2.w * d2n * d2n * k2;
-                const float hd0 = -m0.w * (2.0f * x0 + x1 + x2) * k0;
-                const float hd1 = -m1.w * (x0 + 2.0f * x1 + x2) * k1;
-                const float hd2 = -m2.w * (x0 + x1 + 2.0f * x2) * k2;
+                h0 += -p3.x * d0 * d0 * k0;
+                h1 += -p3.y * d1 * d1 * k1;
+                h2 += -p3.z * d2n * d2n * k2;
+                const float hd0 = -p3.x * (2.0f * x0 + x1 + x2) * k0;
+                const float hd1 = -p3.y * (x0 + 2.0f * x1 + x2) * k1;
+                const float hd2 = -p3.z * (x0 + x1 + 2.0f * x2) * k2;
                 const float dot = hd0 * d0 + hd1 * d1 + hd2 * d2n;  // safe_normalize_bw
                 v0 += il * (hd0 - d0 * dot);
                 v1 += il * (hd1 - d1 * dot);
                 v2 += il * (hd2 - d2n * dot);
-                g[0] = h0 * rex + v0 * rdx; g[1] = h0 * rey + v0 * rdy; g[2] = h0 * rez + v0 * rdz;
-                g[3] = h1 * rex + v1 * rdx; g[4] = h1 * rey + v1 * rdy; g[5] = h1 * rez + v1 * rdz;
-                g[6] = h2 * rex + v2 * rdx; g[7] = h2 * rey + v2 * rdy; g[8] = h2 * rez + v2 * rdz;
+                const float ex_ = kCentred ? 0.0f : rex, ey_ = kCentred ? 0.0f : rey, ez_ = kCentred ? 0.0f : rez;
+                g[0] = h0 * ex_ + v0 * rdx; g[1] = h0 * ey_ + v0 * rdy; g[2] = h0 * ez_ + v0 * rdz;
+                g[3] = h1 * ex_ + v1 * rdx; g[4] = h1 * ey_ + v1 * rdy; g[5] = h1 * ez_ + v1 * rdz;
+                g[6] = h2 * ex_ + v2 * rdx; g[7] = h2 * ey_ + v2 * rdy; g[8] = h2 * ez_ + v2 * rdz;
             }
             g[9] = h0; g[10] = h1; g[11] = h2;
             T = Tn;  // unchanged for lanes that did not hit
@@ -604,17 +644,18 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             uint32_t ja = list[0], jb = list[1];
-            float4 a0 = stage_at(stage, ja).mu_sigma, a1 = stage_at(stage, ja).m0, a2 = stage_at(stage, ja).m1, a3 = stage_at(stage, ja).m2;
+            // (without the hit-distance terms only q3.w = m22 is used: the compiler keeps one dword of the fourth read)
+            float4 a0 = stage_at(stage, ja).q0, a1 = stage_at(stage, ja).q1, a2 = stage_at(stage, ja).q2, a3 = stage_at(stage, ja).q3;
             float4 b0, b1, b2, b3;
             uint32_t i = 0;
             while (i < nw) {
                 if (__ballot(alive) == 0ull) break;
-                b0 = stage_at(stage, jb).mu_sigma; b1 = stage_at(stage, jb).m0; b2 = stage_at(stage, jb).m1; b3 = stage_at(stage, jb).m2;
+                b0 = stage_at(stage, jb).q0; b1 = stage_at(stage, jb).q1; b2 = stage_at(stage, jb).q2; b3 = stage_at(stage, jb).q3;
                 const uint32_t jc = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(a0, a1, a2, a3, ja);
                 if (++i >= nw) break;
                 if (__ballot(alive) == 0ull) break;
-                a0 = stage_at(stage, jc).mu_sigma; a1 = stage_at(stage, jc).m0; a2 = stage_at(stage, jc).m1; a3 = stage_at(stage, jc).m2;
+                a0 = stage_at(stage, jc).q0; a1 = stage_at(stage, jc).q1; a2 = stage_at(stage, jc).q2; a3 = stage_at(stage, jc).q3;
                 const uint32_t jd = list[min(i + 2, (uint32_t)kBlock - 1)];
                 entry(b0, b1, b2, b3, jb);
                 ++i;
@@ -690,6 +731,8 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             if (kDistGrad && k < 4) acc[e * W + 16 + k] = 0.0f;
         }
     }
+    };
+    if (centred) walk(std::true_type{}); else walk(std::false_type{});
 
     atomicMax(&s_deepest, consumed);
     __syncthreads();

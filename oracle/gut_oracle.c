@@ -840,6 +840,15 @@ static float hit_noise(const Hit* h, const float* s) {
 /* K6: render — gutRenderer.cuh:83-115, gutKBufferRenderer.cuh:108-170,217-292 (K=0),
  * rayPayload.cuh:110-129.  Also returns per-tile traversal counts (entries fetched before the
  * whole tile terminated) for the roofline statistics E_f. */
+/* tests only: per-pixel FLIP BUDGET of the next oracle_render_margins call.  g_pixel_budget_out[2 pix] = how far a different but equally
+ * valid fp32 evaluation may move the pixel's colour / opacity / (relative) hit distance because hit / no-hit decisions within
+ * g_pixel_budget_bound noise widths of their thresholds flip: sum over those entries of 2 alpha T (a flipped hit adds or removes
+ * alpha T (colour - what lies behind it), colours of magnitude <= 2), plus 2 T where the ray's termination is that close to its
+ * threshold; [2 pix + 1] = by how many hits the count may differ (one per such entry; 64 more if the termination may flip). */
+static float* g_pixel_budget_out = NULL;
+static float g_pixel_budget_bound = 0.0f;
+void oracle_set_pixel_budget_out(float* p, float bound) { g_pixel_budget_out = p; g_pixel_budget_bound = bound; }
+
 /* tests only: when set, the next render / render_bwd also writes each tile's traversal depth (list entries fetched before every ray
  * of the tile had ended) there; the totals they return are the sums */
 static uint32_t* g_tile_traversed_out = NULL;
@@ -867,6 +876,8 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                 uint32_t nh = 0;
                 uint32_t k = beg;
                 float m_thr = 3.4028235e+38f, m_trm = 3.4028235e+38f, t_noise = 1.0f; /* decision margins, see oracle_render_margins */
+                float pb = 0.0f, pb_hits = 0.0f;   /* pixel flip budget (g_pixel_budget_out) */
+                int pb_term = 0;
                 for (; k < end && ray.alive; ++k) {
                     const uint32_t id = sorted_ids[k];
                     if (id == INVALID_IDX) break;
@@ -882,10 +893,13 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                         const float eps = 5.9604645e-08f;
                         const float mr = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu);
                         if (mr < m_thr) m_thr = mr;
+                        float me = mr;
                         if (h.resp > prm->min_kernel_density) {
                             const float ma = fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu);
                             if (ma < m_thr) m_thr = ma;
+                            if (ma < me) me = ma;
                         }
+                        if (g_pixel_budget_out && me < g_pixel_budget_bound) { pb += 2.0f * h.alpha * T; pb_hits += 1.0f; }
                     }
                     if ((h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold)) {
                         const float* s = g + 8;
@@ -908,6 +922,7 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                                 t_noise += h.alpha * nu / (1.0f - h.alpha) + 1.0f;
                                 const float mt = fabsf(T - prm->min_transmittance) / (prm->min_transmittance * 5.9604645e-08f * t_noise);
                                 if (mt < m_trm) m_trm = mt;
+                                if (g_pixel_budget_out && mt < g_pixel_budget_bound && !pb_term) { pb_term = 1; pb += 2.0f * T; pb_hits += 64.0f; }
                             }
                             if (T < prm->min_transmittance) ray.alive = 0;
                         }
@@ -919,6 +934,7 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                 dist[pix] = dsum;
                 hits[pix] = (float)nh;
                 if (margins) { margins[2 * pix] = m_thr; margins[2 * pix + 1] = m_trm; }
+                if (margins && g_pixel_budget_out) { g_pixel_budget_out[2 * pix] = pb; g_pixel_budget_out[2 * pix + 1] = pb_hits; }
             }
         traversed_total += deepest;
         if (g_tile_traversed_out) g_tile_traversed_out[tile] = deepest;

@@ -183,8 +183,10 @@ def debug_ray(cam: dict, fwd: dict, px, py, params=None, max_entries=4096):
     return out[:n]
 
 
-def render_margins(cam: dict, fwd: dict, params=None):
-    """Per-pixel decision margins of a forward() result's compositing (oracle_render_margins): [H,W,2] float32,
+def render_margins(cam: dict, fwd: dict, params=None, budget_bound=None):
+    """budget_bound (e.g. 12.0): returns (margins, budget) with budget [H,W,2] float32 = the per-pixel flip budget (how far decisions
+    within that many noise widths of a threshold may move the pixel's colour; by how many hits its count may differ), see gut_oracle.c.
+    Per-pixel decision margins of a forward() result's compositing (oracle_render_margins): [H,W,2] float32,
     channel 0 = hit/no-hit thresholds (min_response, min_alpha), channel 1 = early termination (min_transmittance),
     both in units of the estimated fp32 noise of the compared quantity (< ~1: a different but equally valid fp32 evaluation
     of the same formula may decide differently)."""
@@ -194,11 +196,15 @@ def render_margins(cam: dict, fwd: dict, params=None):
     d12, sph, ro, rd, sh_degree, W, H = fwd["_inputs"]
     rgba = np.zeros((H, W, 4), np.float32); dist = np.full((H, W, 1), 1e6, np.float32); hits = np.zeros((H, W, 1), np.float32)
     margins = np.full((H, W, 2), np.finfo(np.float32).max, np.float32)
+    budget = np.zeros((H, W, 2), np.float32) if budget_bound is not None else None
     if fwd["M"]:
+        if budget is not None:
+            L.oracle_set_pixel_budget_out(_p(budget), C.c_float(float(budget_bound)))
         L.oracle_render_margins(C.byref(prm), C.byref(c), C.c_int(W), C.c_int(H), _p(d12), _p(fwd["feat"]), _p(ro), _p(rd),
                                 _p(fwd["tile_ranges"]), _p(fwd["sorted_ids"]), _p(rgba), _p(dist), _p(hits), _p(margins))
+        L.oracle_set_pixel_budget_out(None, C.c_float(0.0))
         assert np.array_equal(rgba, fwd["rgba"])
-    return margins
+    return margins if budget is None else (margins, budget)
 
 
 def render_kbuffer(cam: dict, fwd: dict, K=16, params=None, max_order=0):

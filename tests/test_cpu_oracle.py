@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import (COLOUR_TOL, FISHEYE_DIST, FLIP_MARGIN_BOUND, GRAD_BLOCKS, K_BAND, ROW_ABS, ROW_FLIP, ROW_FLIP_BOUND, ROW_NOISE, ROW_REL, cams,
+from tests.common import (COLOUR_TOL, FISHEYE_DIST, FLIP_MARGIN_BOUND, GRAD_BLOCKS, K_BAND, PIX_FLIP, ROW_ABS, ROW_FLIP, ROW_FLIP_BOUND, ROW_NOISE, ROW_REL, cams,
                           densified_like_scene, fisheye_max_angle_edge_case, make_view, pose, scenes)
 
 oracle = importlib.import_module("oracle.oracle")
@@ -382,7 +382,8 @@ def test_two_fp32_evaluations_measure_the_tolerance_model(name):
     rg = rng.normal(size=(H, W, 4)).astype(np.float32)
     dg = (0.1 * rng.normal(size=(H, W, 1))).astype(np.float32)
     A = oracle.forward(cam, W, H, d12, sph, view["ro"], view["rd"])
-    margins = oracle.render_margins(cam, A).min(-1)
+    margins2, pixel_budget = oracle.render_margins(cam, A, budget_bound=ROW_FLIP_BOUND)
+    margins = margins2.min(-1)
     gA, sA, _, budget = oracle.backward(cam, A, rg, dg, flip_bound=ROW_FLIP_BOUND)
     report = {}
     for v in (1, 2):
@@ -399,7 +400,14 @@ def test_two_fp32_evaluations_measure_the_tolerance_model(name):
         assert worst_margin <= FLIP_MARGIN_BOUND / K_BAND, (name, v, worst_margin)
         worst_calm_pixel = float(diff[margins >= FLIP_MARGIN_BOUND / K_BAND].max())
         assert worst_calm_pixel <= COLOUR_TOL / 2.0, (name, v, worst_calm_pixel)    # the flat colour tolerance: measured 8.7e-5 of 2e-4
-        rep = dict(pixel_outliers=int(out.sum()), worst_flip_margin=round(worst_margin, 2), worst_calm_pixel=worst_calm_pixel)
+        # ... and, quantitatively, every pixel stays within COLOUR_TOL + PIX_FLIP x its own flip budget (what its near-threshold entries
+        # can move it by), hit counts within the number of such entries — with K_BAND to spare
+        ddist = np.abs(A["dist"] - B["dist"])[..., 0] / max(1.0, float(np.abs(A["dist"]).max()))
+        worst_budget = float((np.maximum(diff, ddist) / (COLOUR_TOL + PIX_FLIP * pixel_budget[..., 0])).max())
+        assert worst_budget <= 0.5, (name, v, worst_budget)     # (a calm pixel at 8.7e-5 of the flat 2e-4 sets this: 0.43)
+        assert bool((np.abs(A["hits"] - B["hits"])[..., 0] <= pixel_budget[..., 1]).all())
+        rep = dict(pixel_outliers=int(out.sum()), worst_flip_margin=round(worst_margin, 2), worst_calm_pixel=worst_calm_pixel,
+                   worst_pixel_vs_budget=round(worst_budget, 3))
         # gradient rows
         for j, (block, sl) in enumerate(GRAD_BLOCKS):
             a, b = gA[:, sl], gB[:, sl]

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import FISHEYE_DIST, cams, check_colour_outliers, make_view, rel_l2, scenes
+from tests.common import FISHEYE_DIST, ROW_FLIP_BOUND, cams, check_colour_outliers, make_view, rel_l2, scenes
 from tests.test_gpu_parity import DIST, _activated_grads, _oracle_inputs, _run_gpu
 
 pytestmark = pytest.mark.gpu
@@ -68,9 +68,10 @@ def test_random_configuration_matches_the_oracle(seed):
     out = res["out"]
     rgba = np.concatenate([out["pred_rgb"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
     if ref["M"]:
-        margins = oracle.render_margins(view["oracle_cam"], ref)
-        check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"fuzz {seed}",
-                              max_prone=0.3)   # the ill-conditioned draws (needles, 2e-4 scales) have wide noise bands
+        margins, pixel_budget = oracle.render_margins(view["oracle_cam"], ref, budget_bound=ROW_FLIP_BOUND)
+        # quantitative form: the ill-conditioned draws (needles, 2e-4 scales) have wide noise bands — a large share of their pixels has
+        # some decision near a threshold, and each is allowed what those decisions can move it by
+        check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"fuzz {seed}", budget=pixel_budget)
     else:
         assert np.abs(rgba - ref["rgba"]).max() == 0.0
     st = raster.stats()

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import FISHEYE_DIST, cams, check_colour_outliers, fisheye_max_angle_edge_case, make_view, rel_l2, scenes, to_batch
+from tests.common import FISHEYE_DIST, ROW_FLIP_BOUND, cams, check_colour_outliers, fisheye_max_angle_edge_case, make_view, rel_l2, scenes, to_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -156,8 +156,8 @@ def test_forward_buffers_and_image(name):
     op = res["out"]["pred_opacity"][0].detach().cpu().numpy()
     d = res["out"]["pred_dist"][0].detach().cpu().numpy()
     hits = res["out"]["hits_count"][0].detach().cpu().numpy()
-    rep = check_colour_outliers(np.concatenate([rgb, op], -1), hits, ref, oracle.render_margins(view["oracle_cam"], ref), label=name,
-                                max_prone=0.2, dist_gpu=d)
+    margins, pixel_budget = oracle.render_margins(view["oracle_cam"], ref, budget_bound=ROW_FLIP_BOUND)
+    rep = check_colour_outliers(np.concatenate([rgb, op], -1), hits, ref, margins, label=name, dist_gpu=d, budget=pixel_budget)
     assert rep["outliers"] <= 1e-3 * rep["pixels"]
     assert st["traversed_fwd"] == ref["traversed_fwd"]
 
@@ -327,8 +327,8 @@ def test_config_toggles_against_the_oracle(name, toggle):
         exp = np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)
         assert np.array_equal(got, exp), f"{key}: {(got != exp).sum()} of {got.size} words differ"
     rgba = np.concatenate([out["pred_rgb"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
-    margins = oracle.render_margins(view["oracle_cam"], ref, params=prm)
-    check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"{name}/{toggle}", max_prone=0.2)
+    margins, pixel_budget = oracle.render_margins(view["oracle_cam"], ref, params=prm, budget_bound=ROW_FLIP_BOUND)
+    check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"{name}/{toggle}", budget=pixel_budget)
     assert st["traversed_fwd"] == ref["traversed_fwd"]
     rg = torch.as_tensor(rgba_grad, device=DEV)
     loss = (out["pred_rgb"][0] * rg[..., :3]).sum() + (out["pred_opacity"][0] * rg[..., 3:]).sum() + \

@@ -93,10 +93,10 @@ def test_workload_against_the_oracle(workload):
     walked = ordered != 0xFFFFFFFF
     assert walked.sum() >= stats["traversed_fwd"] and np.array_equal(ordered[walked], ref["sorted_ids"][walked])
     # image: 2e-4, outliers attributed to threshold flips by the oracle's own decision margins
-    margins = oracle.render_margins(ocam, ref)
+    margins, pixel_budget = oracle.render_margins(ocam, ref, budget_bound=ROW_FLIP_BOUND)
     # traversal depths: per tile, equal to the oracle's except where a termination is within fp32 noise of its threshold
     check_tile_traversal(raster.debug_buffer("tile_traversed_fwd").cpu().numpy().view(np.uint32), ref["tile_traversed_fwd"], margins, W, H, workload)
-    check_colour_outliers(rgba.cpu().numpy(), hits.cpu().numpy(), ref, margins, label=workload)
+    check_colour_outliers(rgba.cpu().numpy(), hits.cpu().numpy(), ref, margins, label=workload, budget=pixel_budget)
     d_gpu, d_ref = dist.cpu().numpy().reshape(H, W), ref["dist"].reshape(H, W)
     calm = margins.min(-1) >= 4.0
     assert np.abs(d_gpu - d_ref)[calm].max() <= 2e-3 * max(1.0, float(np.abs(d_ref).max()))
