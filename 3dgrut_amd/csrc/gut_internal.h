@@ -100,13 +100,15 @@ void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, co
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                    const uint32_t* sorted_ids, const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits,
                    uint32_t* tile_traversed, const uint64_t* tile_keys /* lazy order only */, uint32_t* ordered_ids /* NULL = list is fully sorted */,
-                   uint32_t* tile_ordered /* lazy order: entries of each tile's list written to ordered_ids */);
+                   uint32_t* tile_ordered /* lazy order: entries of each tile's list written to ordered_ids */,
+                   const uint32_t* tile_order = nullptr /* launch order of the tiles (longest lists first) or NULL */);
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
                        float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order,
                        const uint32_t* tile_walked /* forward's per-tile traversal depth: the backward stops there */);
-void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order);
+void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order, const uint32_t* ranges = nullptr,
+                       bool by_length = false, uint32_t* walk_sums = nullptr);
 // sorted (k_buffer_size > 0) compositor variant, gut_render_sorted.hip
 void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
                           const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,

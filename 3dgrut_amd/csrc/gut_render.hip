@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                                                      float4* __restrict__ rgba, float* __restrict__ dist,
                                                      float* __restrict__ hits, uint32_t* __restrict__ tile_traversed,
                                                      const uint2* __restrict__ tile_keys, uint32_t* __restrict__ ordered_ids,
-                                                     uint32_t* __restrict__ tile_ordered) {
+                                                     uint32_t* __restrict__ tile_ordered, const uint32_t* __restrict__ tile_order) {
     __shared__ PackEntry stage[kBlock];
     __shared__ uint32_t s_deepest, s_first_invalid;
     __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (8x8 blocks) can hit it at all
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     __shared__ StripPlanes s_planes;
     __shared__ LazyOrder s_lazy;
 
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (optional) longest lists first
     const uint32_t tid = threadIdx.x;
     const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + tile_px(tid);   // wave = 8x8 block (gut_render_common.h)
     const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + tile_py(tid);
@@ -743,33 +743,49 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
                    const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed,
-                   const uint64_t* tile_keys, uint32_t* ordered_ids, uint32_t* tile_ordered) {
+                   const uint64_t* tile_keys, uint32_t* ordered_ids, uint32_t* tile_ordered, const uint32_t* tile_order) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     auto kern = ordered_ids != nullptr ? k_render<true> : k_render<false>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12), feat,
                        ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, d_num_intersections,
                        reinterpret_cast<float4*>(rgba), dist, hits, tile_traversed, reinterpret_cast<const uint2*>(tile_keys),
-                       ordered_ids, tile_ordered);
+                       ordered_ids, tile_ordered, tile_order);
 }
 
 // Launch order for the backward: tiles by decreasing forward traversal depth (the backward walks exactly as deep),
 // longest-processing-time-first, so the few deep tiles do not become the tail of the grid.  One workgroup: 256
 // linear buckets between 0 and the deepest tile, counting sort in LDS; the order inside a bucket is irrelevant.
-__global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const uint32_t* __restrict__ traversed,
-                                                     uint32_t* __restrict__ order) {
-    __shared__ uint32_t s_max, s_hist[256], s_base[256];
+// by_length: the key is the tile's list LENGTH — the forward's order, known before anything has been walked.
+// walk_sums (may be null; backward order only): [0] = sum of the traversal depths, [1] = sum of the list lengths of this frame — the
+// share of the lists the forward walked, which the host reads with the next frame's count and uses to decide whether the forward
+// compositor of the frames after it is launched longest-lists-first (it pays when most of every list is walked).
+__global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const uint32_t* __restrict__ traversed_in,
+                                                     uint32_t* __restrict__ order, const uint2* __restrict__ ranges, bool by_length,
+                                                     uint32_t* __restrict__ walk_sums) {
+    __shared__ uint32_t s_max, s_hist[256], s_base[256], s_sum[2];
     const uint32_t tid = threadIdx.x;
+    auto key = [&](uint32_t t) { return by_length ? ranges[t].y - ranges[t].x : traversed_in[t]; };
+    if (walk_sums) {   // (uniform)
+        if (tid < 2) s_sum[tid] = 0;
+        __syncthreads();
+        uint32_t a = 0, b = 0;
+        for (uint32_t t = tid; t < tiles; t += 1024) { a += traversed_in[t]; b += ranges[t].y - ranges[t].x; }
+        for (int o = 32; o > 0; o >>= 1) { a += (uint32_t)__shfl_xor((int)a, o); b += (uint32_t)__shfl_xor((int)b, o); }
+        if ((tid & 63) == 0) { atomicAdd(&s_sum[0], a); atomicAdd(&s_sum[1], b); }
+        __syncthreads();
+        if (tid < 2) walk_sums[tid] = s_sum[tid];
+    }
     if (tid == 0) s_max = 0;
     if (tid < 256) s_hist[tid] = 0;
     __syncthreads();
     uint32_t mx = 0;
-    for (uint32_t t = tid; t < tiles; t += 1024) mx = max(mx, traversed[t]);
+    for (uint32_t t = tid; t < tiles; t += 1024) mx = max(mx, key(t));
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
     if ((tid & 63) == 0) atomicMax(&s_max, mx);
     __syncthreads();
     const uint32_t width = s_max / 256 + 1;
-    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&s_hist[255 - min(255u, traversed[t] / width)], 1u);
+    for (uint32_t t = tid; t < tiles; t += 1024) atomicAdd(&s_hist[255 - min(255u, key(t) / width)], 1u);
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
@@ -779,12 +795,14 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const uint3
         }
     }
     __syncthreads();
-    for (uint32_t t = tid; t < tiles; t += 1024) order[atomicAdd(&s_base[255 - min(255u, traversed[t] / width)], 1u)] = t;
+    for (uint32_t t = tid; t < tiles; t += 1024) order[atomicAdd(&s_base[255 - min(255u, key(t) / width)], 1u)] = t;
 }
 
-void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order) {
+void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order, const uint32_t* ranges, bool by_length,
+                       uint32_t* walk_sums) {
     if (tiles == 0) return;
-    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tiles, traversed, order);
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tiles, traversed, order, reinterpret_cast<const uint2*>(ranges), by_length,
+                       ranges ? walk_sums : nullptr);
 }
 
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
