@@ -20,6 +20,7 @@ ADAM_CLEAR_CONSUMED_GRADS = 1
 GRADIENT_RECORD_FLOATS = 16
 OPT_SORTED_REFERENCE_BACKWARD = 2
 OPT_EARLY_EXTRA_PERCENT = 3
+OPT_FORWARD_TILE_ORDER = 4
 OPT_DEBUG_REPLACE_SCRATCH = 100
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer",
                       "optimizer_early", "optimizer_early_2")
@@ -29,7 +30,7 @@ CAMERA_PINHOLE, CAMERA_FISHEYE = 0, 1
 
 BUF = dict(tiles_count=0, tiles_offset=1, proj_pos=2, conic_opacity=3, extent=4, depth=5, feat=6,
            unsorted_keys=7, unsorted_ids=8, sorted_keys=9, sorted_ids=10, tile_ranges=11, grad_scratch=12,
-           tile_traversed_fwd=13, tile_traversed_bwd=14, ordered_ids=15)
+           tile_traversed_fwd=13, tile_traversed_bwd=14, ordered_ids=15, packed_rows=16)
 
 
 class GutCamera(C.Structure):
@@ -77,7 +78,7 @@ EXPORTS = ("gut_default_config", "gut_create", "gut_destroy", "gut_trace", "gut_
            "gut_sh_adam_step_ex", "gut_mark_walked_waves", "gut_adam_unwalked_waves", "gut_activate_pack", "gut_adam_step", "gut_sh_adam_step", "gut_mcmc_relocation",
            "gut_optimize_finish_without_gradient", "gut_scatter_gradient_records_dev", "gut_adam_unwalked_waves_ex", "gut_sync_moments", "gut_trace_fields", "gut_trace_bwd_fields", "gut_selective_adam",
            "gut_trace_model_fields", "gut_trace_bwd_model_fields", "gut_position_gradient_statistics",
-           "gut_set_position_gradient_statistics", "gut_mcmc_perturb")
+           "gut_set_position_gradient_statistics", "gut_mcmc_perturb", "gut_trace_raw_model_fields")
 
 _lib = None
 
@@ -87,11 +88,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # (GUT_HIP_LIBRARY: a developer's diagnostic build of the same sources, e.g. tools/clock_probe.py's stamped library)
+    path = os.environ.get("GUT_HIP_LIBRARY") or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the 3DGUT HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"{path} is missing: the 3DGUT HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (needs hipcc). There is no CPU fallback in the product path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, u32, i32, f_p = C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p
     lib.gut_last_error.restype = C.c_char_p
     lib.gut_abi_version.restype = C.c_int
@@ -108,6 +111,7 @@ def load():
                                          f_p, f_p, f_p, f_p, f_p]
     lib.gut_trace_model_fields.argtypes = [vp, vp, u32, i32, u32, f_p, f_p, f_p, f_p, f_p, f_p, i32, i32, f_p, f_p, C.POINTER(GutCamera),
                                            f_p, f_p, f_p, f_p]
+    lib.gut_trace_raw_model_fields.argtypes = lib.gut_trace_model_fields.argtypes
     lib.gut_trace_bwd_model_fields.argtypes = [vp, vp, u32, i32, u32, i32, i32, f_p, f_p, C.POINTER(GutCamera), f_p, f_p, f_p, f_p,
                                                f_p, f_p, f_p, f_p, f_p, f_p]
     lib.gut_position_gradient_statistics.argtypes = [vp, u32, f_p, u32, f_p, u32, f_p, f_p, vp]

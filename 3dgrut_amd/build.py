@@ -34,6 +34,23 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def build_diagnostic(out, defines, verbose=False):
+    """A diagnostic build of the same sources with extra -D flags into `out` (its own object directory); tools only."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    obj_dir = out + ".obj"
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = []
+    for src, extra in UNITS:
+        o = os.path.join(obj_dir, src + ".o")
+        objs.append(o)
+        cmd = [hipcc] + COMMON + extra + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)

@@ -138,6 +138,7 @@ struct gut_context {
     int32_t* stat_denom = nullptr;
     DevBuf packed12;   // gut_trace_fields: the [N,12] rows packed from the caller's four tensors (kept for its backward)
     bool packed_valid = false;
+    bool packed_raw = false;   // packed12 holds rows ACTIVATED by the library from the model's raw tensors (gut_trace_raw_model_fields)
     // per-M scratch
     DevBuf keys_unsorted, keys_sorted, ids_unsorted, ids_sorted, sort_temp;
     // lazy per-tile depth order (unsorted variant): keys_sorted / ids_sorted are grouped by tile only, the forward compositor
@@ -184,6 +185,7 @@ struct gut_context {
     uint64_t overflows = 0;
     DevBuf zero_word, tile_ordered, walk_sums;
     bool fwd_longest_first = false;   // forward compositor launched longest-lists-first (decided from the last frames' walked share)
+    int fwd_order_mode = -1;          // GUT_OPT_FORWARD_TILE_ORDER: -1 auto, 0 image order, 1 longest first
     bool dbg_ordered_valid = false;
 
     // cached forward context (gutRenderer.cu:252-254, 413)
@@ -584,8 +586,7 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
             // untouched (headline stand-in, E/M = 0.12) the length says little and the natural order keeps neighbouring tiles, which
             // share Gaussians, together in time (0.52 -> 0.53 ms with the order, plus its 8 us launch).  The walked share comes from
             // the backward's own ordering kernel (walk_sums), read back with the intersection count: no extra synchronisation.
-            static const int fwd_order_env = getenv("GUT_FWD_TILE_ORDER") ? atoi(getenv("GUT_FWD_TILE_ORDER")) : -1;   // 0 / 1 force it
-            const bool fwd_order = fwd_order_env >= 0 ? fwd_order_env != 0 : h->fwd_longest_first;
+            const bool fwd_order = h->fwd_order_mode >= 0 ? h->fwd_order_mode != 0 : h->fwd_longest_first;   // GUT_OPT_FORWARD_TILE_ORDER
             if (fwd_order && sort_n)
                 gut::launch_tile_order(s, (uint32_t)tiles, nullptr, h->tile_order.as<uint32_t>(), h->ranges.as<uint32_t>(), true);
             gut::launch_render(s, v, h->consts, d_particle_density, h->feat.as<float>(), d_ray_origin, d_ray_direction,
@@ -717,6 +718,7 @@ int gut_trace_fields(gut_handle h, void* stream_, uint32_t frame_number, int32_t
         DeviceGuard dev_guard;
         HIP_TRY(dev_guard.set(h->device));
         h->packed_valid = false;
+        h->packed_raw = false;
         HIP_TRY(h->packed12.ensure(sizeof(float) * 12 * (size_t)num_particles + 64));
         gut::launch_pack_fields(static_cast<hipStream_t>(stream_), num_particles, d_positions, d_density, d_rotation, d_scale,
                                 h->packed12.as<float>());
@@ -768,6 +770,7 @@ int gut_trace_model_fields(gut_handle h, void* stream_, uint32_t frame_number, i
         DeviceGuard dev_guard;
         HIP_TRY(dev_guard.set(h->device));
         h->packed_valid = false;
+        h->packed_raw = false;
         HIP_TRY(h->packed12.ensure(sizeof(float) * 12 * (size_t)num_particles + 64));
         gut::launch_pack_fields(static_cast<hipStream_t>(stream_), num_particles, d_positions, d_density, d_rotation, d_scale,
                                 h->packed12.as<float>());
@@ -778,6 +781,40 @@ int gut_trace_model_fields(gut_handle h, void* stream_, uint32_t frame_number, i
                                   d_ray_hit_distance, d_ray_hit_count, d_particle_visibility,
                                   num_particles ? d_features_albedo : nullptr);
     if (rc == 0) h->packed_valid = true;
+    return rc;
+}
+
+// gut_trace_model_fields on the model's PRE-ACTIVATION tensors (model.py:74-93: density logit, un-normalised quaternion, log-scale):
+// sigmoid / normalize / exp and the packing run as one kernel (k_pack_activate_fields), and the backward that follows
+// (gut_trace_bwd_model_fields on this handle) returns the gradients w.r.t. those raw tensors (K8 <raw, split>): the model's three
+// activation kernels, their three backward kernels and autograd's bookkeeping for them drop out of the reference trainer's step.
+int gut_trace_raw_model_fields(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                               const float* d_positions, const float* d_density_logit, const float* d_rotation_raw, const float* d_log_scale,
+                               const float* d_features_albedo, const float* d_features_specular, int32_t width, int32_t height,
+                               const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                               float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+                               float* d_particle_visibility) {
+    if (!h) return fail("gut_trace_raw_model_fields: null handle");
+    if (num_particles && (!d_positions || !d_density_logit || !d_rotation_raw || !d_log_scale || !d_features_albedo || !d_features_specular))
+        return fail("gut_trace_raw_model_fields: null particle buffers with %u particles", num_particles);
+    if ((((uintptr_t)d_rotation_raw | (uintptr_t)d_features_specular) & 15u) != 0)
+        return fail("gut_trace_raw_model_fields: the rotation and features_specular tensors must be 16-byte aligned");
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        DeviceGuard dev_guard;
+        HIP_TRY(dev_guard.set(h->device));
+        h->packed_valid = false;
+        h->packed_raw = false;
+        HIP_TRY(h->packed12.ensure(sizeof(float) * 12 * (size_t)num_particles + 64));
+        gut::launch_pack_activate_fields(static_cast<hipStream_t>(stream_), num_particles, d_positions, d_density_logit, d_rotation_raw,
+                                         d_log_scale, h->packed12.as<float>());
+        HIP_TRY(hipGetLastError());
+    }
+    const int rc = trace_fwd_impl(h, stream_, frame_number, num_active_features, num_particles, h->packed12.as<float>(),
+                                  d_features_specular, width, height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density,
+                                  d_ray_hit_distance, d_ray_hit_count, d_particle_visibility,
+                                  num_particles ? d_features_albedo : nullptr);
+    if (rc == 0) { h->packed_valid = true; h->packed_raw = true; }
     return rc;
 }
 
@@ -797,9 +834,11 @@ int gut_trace_bwd_model_fields(gut_handle h, void* stream_, uint32_t frame_numbe
     gut::GradFields f;
     f.pos = d_positions_grad; f.dns = d_density_grad; f.rot = d_rotation_grad; f.scl = d_scale_grad;
     f.alb = d_features_albedo_grad; f.spec = d_features_specular_grad;
+    // (after gut_trace_raw_model_fields the rows carry |quat| in the pad column and the gradients are chained to the raw tensors)
     return trace_bwd_impl(h, stream_, frame_number, num_active_features, num_particles, h->packed12.as<float>(), nullptr, width,
                           height, d_ray_origin, d_ray_direction, camera, d_ray_radiance_density, d_ray_radiance_density_grad,
-                          d_ray_hit_distance, d_ray_hit_distance_grad, d_positions_grad /* non-null markers */, d_features_specular_grad, 0u, f);
+                          d_ray_hit_distance, d_ray_hit_distance_grad, d_positions_grad /* non-null markers */, d_features_specular_grad,
+                          h->packed_raw ? GUT_BWD_RAW_PARAMETER_GRADS : 0u, f);
 }
 
 static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
@@ -1148,6 +1187,10 @@ int gut_set_option(gut_handle h, int32_t option, int32_t value) {
     switch (option) {
     case GUT_OPT_LAZY_TILE_ORDER: h->lazy_enabled = value != 0; return 0;
     case GUT_OPT_SORTED_REFERENCE_BACKWARD: h->sorted_reference_bwd = value != 0; return 0;
+    case GUT_OPT_FORWARD_TILE_ORDER:
+        if (value < -1 || value > 1) return fail("gut_set_option: GUT_OPT_FORWARD_TILE_ORDER takes -1, 0 or 1");
+        h->fwd_order_mode = value;
+        return 0;
     case GUT_OPT_EARLY_EXTRA_PERCENT:
         if (value < 0 || value > 100) return fail("gut_set_option: GUT_OPT_EARLY_EXTRA_PERCENT takes 0..100");
         h->early_extra_percent = value;
@@ -1322,6 +1365,9 @@ int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes) {
             h->dbg_ordered_valid = true;
         }
         *d_ptr = h->lazy_order ? h->ids_ordered.p : h->ids_sorted.p; *bytes = 4 * m; break;
+    case GUT_BUF_PACKED_ROWS:
+        if (!h->packed_valid) return fail("gut_debug_buffer: the last forward was not a field-wise one (no packed rows)");
+        *d_ptr = h->packed12.p; *bytes = 48 * n; break;
     case GUT_BUF_TILE_RANGES: *d_ptr = h->ranges.p; *bytes = 8 * t; break;
     case GUT_BUF_GRAD_SCRATCH:
         if (!h->have_backward) return fail("gut_debug_buffer: no backward yet");

@@ -95,6 +95,8 @@ void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_d
                         float* density_grad12, float* sph_grad48, bool raw_grads, const GradFields& fields = GradFields());
 void launch_pack_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns, const float* rot, const float* scl,
                         float* density12);
+void launch_pack_activate_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns_logit, const float* rot_raw,
+                                 const float* log_scl, float* act12);   // gut_train.hip (activate_row)
 
 void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                    const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,

@@ -1020,7 +1020,7 @@ void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_d
                         float* sph_grad48, bool raw_grads, const GradFields& fields) {
     if (n == 0) return;
     auto kern = raw_grads ? k_project_backward<true, false> : k_project_backward<false, false>;
-    if (fields.spec) kern = k_project_backward<false, true>;   // (gut_trace_bwd_model_fields: activated-parameter gradients only)
+    if (fields.spec) kern = raw_grads ? k_project_backward<true, true> : k_project_backward<false, true>;   // gut_trace_bwd_model_fields
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), tiles_count, feat,
                        reinterpret_cast<float4*>(grad16), reinterpret_cast<float4*>(density_grad12),

@@ -396,6 +396,14 @@ __device__ __forceinline__ uint32_t reduce_slot(uint32_t lane) { return (lane & 
 
 constexpr int kGradRow = 16;  // floats per global gradient row: pos3, density, quat4, scale3, rgb3, pad2
 
+#ifdef GUT_CLOCK_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/clock_probe.py builds tools/bin/libgut_hip_stamps.so with -DGUT_CLOCK_STAMPS; the product library
+// has none of this): every workgroup of the backward compositor stamps the shader clock (s_memtime, cycles) and the constant
+// 100 MHz counter (s_memrealtime) at its start and end into a buffer no other code reads — delta cycles / delta real time is the
+// clock the chip actually held during the launch (MI355X_MICROARCH.md, "DVFS give-back" item 6).
+__device__ unsigned long long g_clock_stamps[8192][4];
+#endif
+
 // accumulator slots inside a chunk row
 //   0..8  A[i][j] = sum h_i m_j     9..11 H_i = sum h_i     12 d(density)     13..15 d(rgb)     [16..18 direct d(scale)]
 template <bool kDistGrad>
@@ -424,10 +432,22 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
     __shared__ uint32_t s_mask[kBlock];              // see k_render
     __shared__ uint16_t s_list[kBlock / 64][kBlock];  // see k_render
     __shared__ StripPlanes s_planes;
+#ifdef GUT_K7_EXTRA_LDS
+    // DIAGNOSTIC BUILD ONLY: ballast that lowers the number of resident workgroups per CU (occupancy experiment, tools/clock_probe.py)
+    __shared__ float s_ballast[GUT_K7_EXTRA_LDS / 4];
+    if (threadIdx.x == 0 && v.width < 0) s_ballast[0] = 1.0f;
+    if (v.width < -1) grad16[0] = s_ballast[threadIdx.x];
+#endif
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // deepest tiles are dispatched first
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
+#ifdef GUT_CLOCK_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_clock_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
+        g_clock_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + tile_px(tid);   // wave = 8x8 block (gut_render_common.h)
     const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + tile_py(tid);
     const bool inside = (px < v.width) && (py < v.height);
@@ -737,6 +757,12 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
     atomicMax(&s_deepest, consumed);
     __syncthreads();
     if (tid == 0) tile_traversed[tile] = s_deepest;
+#ifdef GUT_CLOCK_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) {
+        g_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime();
+        g_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -797,6 +823,15 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const uint3
     __syncthreads();
     for (uint32_t t = tid; t < tiles; t += 1024) order[atomicAdd(&s_base[255 - min(255u, key(t) / width)], 1u)] = t;
 }
+
+#ifdef GUT_CLOCK_STAMPS
+}  // namespace gut
+// diagnostic build only: copies the backward compositor's clock stamps [8192][4] u64 to the host
+extern "C" int gut_debug_clock_stamps(void* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gut::g_clock_stamps), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : 1;
+}
+namespace gut {
+#endif
 
 void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order, const uint32_t* ranges, bool by_length,
                        uint32_t* walk_sums) {

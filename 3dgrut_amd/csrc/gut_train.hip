@@ -28,6 +28,19 @@ __global__ __launch_bounds__(kBlock) void k_activate_pack(uint32_t n, const floa
     activate_row(raw[3 * (size_t)i + 0], raw[3 * (size_t)i + 1], raw[3 * (size_t)i + 2], act + 3 * (size_t)i);
 }
 
+// k_pack_activate_fields: the model's PRE-ACTIVATION tensors (positions [N,3], density logit [N,1], un-normalised quaternion [N,4],
+// log-scale [N,3]; threedgrut/model/model.py:74-93 with base_gs.yaml's sigmoid / normalize / exp) -> the activated [N,12] rows the
+// renderer reads, |quat| in the pad column for the backward's chain rule: the model's three activation kernels and the tracer's
+// torch.cat as one coalesced pass (gut_trace_raw_model_fields)
+__global__ __launch_bounds__(kBlock) void k_pack_activate_fields(uint32_t n, const float* __restrict__ pos, const float* __restrict__ dns,
+                                                                const float4* __restrict__ rot, const float* __restrict__ scl,
+                                                                float4* __restrict__ act) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    activate_row(make_float4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], dns[i]), rot[i],
+                 make_float4(scl[3 * (size_t)i], scl[3 * (size_t)i + 1], scl[3 * (size_t)i + 2], 0.0f), act + 3 * (size_t)i);
+}
+
 struct AdamParams {
     float lr[64];  // per column
     float beta1, beta2, eps;
@@ -901,6 +914,15 @@ __global__ __launch_bounds__(kBlock) void k_sync_moments(uint32_t n, float4* __r
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (lane == 0) lz.wave_step[wave] = lz.t;
+}
+}  // namespace gut
+
+namespace gut {
+void launch_pack_activate_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns, const float* rot, const float* scl,
+                                 float* act12) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pack_activate_fields, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, pos, dns,
+                       reinterpret_cast<const float4*>(rot), scl, reinterpret_cast<float4*>(act12));
 }
 }  // namespace gut
 

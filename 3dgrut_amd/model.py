@@ -19,6 +19,10 @@ class GaussianModel(torch.nn.Module):
         self.density = t(np.log(dens / (1 - dens)))                           # pre-activation: logit
         self.features_albedo = t(feats[:, :3])
         self.features_specular = t(feats[:, 3:])
+        # the reference's activation callables and their names (model.py:163-167, utils/misc.py:45-50, base_gs.yaml:54-55)
+        self.density_activation = torch.sigmoid
+        self.scale_activation = torch.exp
+        self.rotation_activation = torch.nn.functional.normalize
         self.max_n_features = 3
         self.n_active_features = int(sh_degree)
         self.background_color = background_color
@@ -28,14 +32,14 @@ class GaussianModel(torch.nn.Module):
     def num_gaussians(self):
         return self.positions.shape[0]
 
-    def get_rotation(self):
-        return torch.nn.functional.normalize(self.rotation, dim=1)
+    def get_rotation(self, preactivation=False):          # model.py:83-93
+        return self.rotation if preactivation else self.rotation_activation(self.rotation)
 
-    def get_scale(self):
-        return torch.exp(self.scale)
+    def get_scale(self, preactivation=False):
+        return self.scale if preactivation else self.scale_activation(self.scale)
 
-    def get_density(self):
-        return torch.sigmoid(self.density)
+    def get_density(self, preactivation=False):
+        return self.density if preactivation else self.density_activation(self.density)
 
     def get_features_albedo(self):      # model.py:68-72
         return self.features_albedo

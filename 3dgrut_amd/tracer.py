@@ -16,6 +16,7 @@ CPU fallback: without the HIP library every call raises.
 import ctypes as C
 import enum
 import math
+import os
 
 import numpy as np
 import torch
@@ -148,6 +149,20 @@ def config_from_conf(conf) -> "_capi.GutConfig":
     cfg.tight_opacity_bounding = int(bool(g("splat.tight_opacity_bounding", True)))
     cfg.tile_based_culling = int(bool(g("splat.tile_based_culling", True)))
     return cfg
+
+
+def _has_reference_activations(gaussians):
+    """True for a model built like the reference's MixtureOfGaussians under configs/base_gs.yaml:54-55 — nn.Parameters `rotation`,
+    `scale`, `density` [N,4] / [N,3] / [N,1] whose activation callables are exactly torch's normalize / exp / sigmoid
+    (threedgrut/model/model.py:163-167, utils/misc.py:45-50) — so that the library may apply them itself."""
+    F = torch.nn.functional
+    try:
+        return (gaussians.rotation_activation is F.normalize and gaussians.scale_activation is torch.exp
+                and gaussians.density_activation is torch.sigmoid
+                and gaussians.rotation.dim() == 2 and gaussians.rotation.shape[1] == 4 and gaussians.scale.shape[1] == 3
+                and gaussians.density.shape[1] == 1 and gaussians.rotation.dtype == torch.float32)
+    except AttributeError:
+        return False
 
 
 def _check_f32_cuda(t, name, shape_tail=None):
@@ -331,8 +346,13 @@ class SplatRaster:
         _capi.check(rc, "trace_bwd_fields")
         return pos_g, dns_g, rot_g, scl_g, sph_g
 
+    def trace_raw_model_fields(self, *args):
+        """trace_model_fields() on the model's PRE-ACTIVATION density / rotation / scale tensors (gut_trace_raw_model_fields): the
+        library applies sigmoid / normalize / exp itself and the following trace_bwd_model_fields returns raw-parameter gradients."""
+        return self.trace_model_fields(*args, _raw=True)
+
     def trace_model_fields(self, frame_number, num_active_features, mog_pos, mog_dns, mog_rot, mog_scl, sph_albedo, sph_specular, ray_ori,
-                           ray_dir, sensor_params, ts_start, ts_end, pose_start, pose_end):
+                           ray_dir, sensor_params, ts_start, ts_end, pose_start, pose_end, _raw=False):
         """trace_fields() with the SH coefficients as the model's two tensors (features_albedo [N,3], features_specular [N,45]; model.py:
         68-75) instead of get_features()'s [N,48] torch.cat (gut_trace_model_fields)."""
         ray_ori = _check_f32_cuda(ray_ori, "rayOrigin", (3,))
@@ -354,8 +374,9 @@ class SplatRaster:
         cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
         stream = torch.cuda.current_stream(dev).cuda_stream
         ptr = lambda t: t.data_ptr() if n else None
+        entry = self._lib.gut_trace_raw_model_fields if _raw else self._lib.gut_trace_model_fields
         with torch.cuda.device(dev):
-            rc = self._lib.gut_trace_model_fields(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF, int(num_active_features), n,
+            rc = entry(self._handle, C.c_void_p(stream), int(frame_number) & 0xFFFFFFFF, int(num_active_features), n,
                                                   ptr(mog_pos), ptr(mog_dns), ptr(mog_rot), ptr(mog_scl), ptr(sph_albedo), ptr(sph_specular),
                                                   W, H, ray_ori.data_ptr(), ray_dir.data_ptr(), C.byref(cam), rgba.data_ptr(),
                                                   dist.data_ptr(), hits.data_ptr(), ptr(vis))
@@ -474,6 +495,11 @@ class SplatRaster:
         hold no Gaussian the forward walked (GUT_OPT_EARLY_EXTRA_PERCENT, default 100; 0 = waves without tiles only)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_EARLY_EXTRA_PERCENT, int(percent)), "set_option")
 
+    def set_forward_tile_order(self, mode):
+        """Launch order of the forward compositor's tiles: 1 longest lists first, 0 image order, -1 (default) decided by the library from
+        the share of their lists the last frames walked (GUT_OPT_FORWARD_TILE_ORDER, gut_hip.h)."""
+        _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_FORWARD_TILE_ORDER, int(mode)), "set_option")
+
     def debug_replace_scratch(self, index):
         """Developer probe: move one of the handle's scratch buffers to a fresh allocation (GUT_OPT_DEBUG_REPLACE_SCRATCH, gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_DEBUG_REPLACE_SCRATCH, int(index)), "set_option")
@@ -522,9 +548,11 @@ class Tracer:
     class _Autograd(torch.autograd.Function):
         @staticmethod
         def forward(ctx, tracer_wrapper, frame_id, n_active_features, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl,
-                    mog_dns, mog_sph, sensor_params, sensor_poses, mog_sph_specular=None):
+                    mog_dns, mog_sph, sensor_params, sensor_poses, mog_sph_specular=None, raw_parameters=False):
             """The reference's twelve arguments (tracer.py:161-174); a thirteenth, mog_sph_specular, says that mog_sph is the model's
-            features_albedo [N,3] and this its features_specular [N,45] (Tracer.render below, for models that expose the two)."""
+            features_albedo [N,3] and this its features_specular [N,45] (Tracer.render below, for models that expose the two); a
+            fourteenth, raw_parameters, that mog_rot / mog_scl / mog_dns are the model's PRE-ACTIVATION tensors (un-normalised
+            quaternion, log-scale, density logit) and the library applies normalize / exp / sigmoid itself."""
             ctx.frame_id = frame_id
             ctx.n_active_features = n_active_features
             ctx.sensor_params = sensor_params
@@ -535,7 +563,8 @@ class Tracer:
             if ctx.model_fields:
                 # all six model tensors go to the library as they are (gut_trace_model_fields): no torch.cat of the features
                 # either (1.0 ms per render at 6 M Gaussians), and six gradient tensors come back, nothing for autograd to split
-                rgba, dist, hits, vis = tracer_wrapper.trace_model_fields(
+                trace = tracer_wrapper.trace_raw_model_fields if raw_parameters else tracer_wrapper.trace_model_fields
+                rgba, dist, hits, vis = trace(
                     frame_id, n_active_features, mog_pos, mog_dns, mog_rot, mog_scl, mog_sph.contiguous(), mog_sph_specular.contiguous(),
                     ray_ori.contiguous(), ray_dir.contiguous(), sensor_params, sensor_poses.timestamps_us[0],
                     sensor_poses.timestamps_us[1], sensor_poses.T_world_sensors[0], sensor_poses.T_world_sensors[1])
@@ -580,7 +609,7 @@ class Tracer:
                     ctx.frame_id, ctx.n_active_features, ctx.num_particles, ray_ori, ray_dir, ctx.sensor_params, poses.timestamps_us[0],
                     poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1], rgba, rgba_grd.contiguous(), dist,
                     None if dist_grd is None else dist_grd.contiguous())
-                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, alb_g, None, None, spec_g)
+                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, alb_g, None, None, spec_g, None)
             if ctx.fields:
                 ray_ori, ray_dir, rgba, dist, particle_radiance = ctx.saved_tensors
                 if rgba_grd is None:
@@ -589,7 +618,7 @@ class Tracer:
                     ctx.frame_id, ctx.n_active_features, ctx.num_particles, particle_radiance, ray_ori, ray_dir, ctx.sensor_params,
                     poses.timestamps_us[0], poses.timestamps_us[1], poses.T_world_sensors[0], poses.T_world_sensors[1], rgba,
                     rgba_grd.contiguous(), dist, None if dist_grd is None else dist_grd.contiguous())
-                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, sph_grd, None, None, None)
+                return (None, None, None, None, None, pos_g, rot_g, scl_g, dns_g, sph_grd, None, None, None, None)
             ray_ori, ray_dir, rgba, dist, particle_density, particle_radiance = ctx.saved_tensors
             if rgba_grd is None:
                 rgba_grd = torch.zeros_like(rgba)
@@ -599,7 +628,7 @@ class Tracer:
                 poses.T_world_sensors[1], rgba, rgba_grd.contiguous(), dist, None if dist_grd is None else dist_grd.contiguous())
             pos_g, dns_g, rot_g, scl_g, _ = torch.split(dens_grd, [3, 1, 4, 3, 1], dim=1)  # tracer.py:268-270
             return (None, None, None, None, None, pos_g.contiguous(), rot_g.contiguous(), scl_g.contiguous(),
-                    dns_g.contiguous(), sph_grd, None, None, None)
+                    dns_g.contiguous(), sph_grd, None, None, None, None)
 
     def __init__(self, conf):
         self.device = "cuda"
@@ -607,6 +636,11 @@ class Tracer:
         torch.zeros(1, device=self.device)  # force context creation (tracer.py:292)
         self.tracer_wrapper = SplatRaster(conf)
         self.split_features = True   # False: always go through gaussians.get_features() (the reference's call, kept for A/B tests)
+        # True: a model whose activations ARE torch.sigmoid / F.normalize / torch.exp (the reference's MixtureOfGaussians under
+        # configs/base_gs.yaml) hands its pre-activation tensors over and the library activates them (gut_trace_raw_model_fields)
+        # (GUT_TRACER_RAW_PARAMETERS=0 in the environment: default off — the parity tests, whose oracle is fed torch's own activations
+        #  and compares bit for bit, set it in tests/conftest.py and switch the raw path on where they test it)
+        self.raw_parameters = os.environ.get("GUT_TRACER_RAW_PARAMETERS", "1") != "0"
 
     @property
     def timings(self):
@@ -624,12 +658,24 @@ class Tracer:
             # the reference's model keeps the SH coefficients as two tensors and concatenates them for every render (model.py:74-75):
             # hand the two over as they are (the only difference from tracer.py:317-327)
             features = (gaussians.get_features_albedo().contiguous(), sensor, poses, gaussians.get_features_specular().contiguous())
+            if getattr(self, "raw_parameters", True) and hasattr(self.tracer_wrapper, "trace_raw_model_fields") and _has_reference_activations(gaussians):
+                # the model's own nn.Parameters, activated inside the library: no normalize / exp / sigmoid kernels, none of their
+                # backward kernels (threedgrut/model/model.py:77-93; the result equals those calls up to the last bits of expf)
+                pred_rgba, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
+                    self.tracer_wrapper, frame_id, gaussians.n_active_features, rays_o.contiguous(), rays_d.contiguous(),
+                    gaussians.positions.contiguous(), gaussians.rotation.contiguous(), gaussians.scale.contiguous(),
+                    gaussians.density.contiguous(), *features, True)
+                return self._outputs(gaussians, gpu_batch, rays_d, pred_rgba, pred_dist, hits_count, mog_visibility, train)
         else:
             features = (gaussians.get_features().contiguous(), sensor, poses)
         pred_rgba, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
             self.tracer_wrapper, frame_id, gaussians.n_active_features, rays_o.contiguous(), rays_d.contiguous(),
             gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
             gaussians.get_density().contiguous(), *features)
+        return self._outputs(gaussians, gpu_batch, rays_d, pred_rgba, pred_dist, hits_count, mog_visibility, train)
+
+    def _outputs(self, gaussians, gpu_batch, rays_d, pred_rgba, pred_dist, hits_count, mog_visibility, train):
+        """The seven-key dictionary of tracer.py:329-351."""
         pred_rgb = pred_rgba[..., :3].unsqueeze(0).contiguous()
         pred_opacity = pred_rgba[..., 3:].unsqueeze(0).contiguous()
         pred_dist = pred_dist.unsqueeze(0).contiguous()

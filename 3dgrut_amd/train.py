@@ -91,18 +91,47 @@ class TrainStep:
     def render(self, batch, train=True):
         return self.tracer.render(self.model, batch, train=train, frame_id=self.step_id)
 
+    phase_timing = False    # bench: HIP events between the phases of step() (phase_times_mean)
+
+    def _mark(self, evs):
+        if evs is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+
+    def phase_times_mean(self):
+        """Mean ms per phase over the steps since the last call: `render` = Tracer.render as the trainer calls it (the model's
+        activations and accessors + the plugin's forward), `loss` = the loss forward, `backward` = loss.backward() (loss backward,
+        the plugin's backward, the activations' backward, gradient accumulation), `optimizer` = optimizer.step() + zero_grad()."""
+        evs_all = getattr(self, "_phase_events", [])
+        if not evs_all:
+            return {}
+        torch.cuda.synchronize()
+        names = ("render", "loss", "backward", "optimizer")
+        acc = [sum(e[k].elapsed_time(e[k + 1]) for e in evs_all) / len(evs_all) for k in range(4)]
+        self._phase_events = []
+        return dict(zip(names, acc))
+
     def step(self, batch):
+        evs = [] if self.phase_timing else None
+        self._mark(evs)
         out = self.render(batch, train=True)
+        self._mark(evs)
         loss = photometric_loss(out["pred_rgb"], batch.rgb_gt)
+        self._mark(evs)
         loss.backward()
         if self.world_size > 1:
             self.allreduce_gradients()
+        self._mark(evs)
         if isinstance(self.optimizer, SelectiveAdam):
             assert out["mog_visibility"].shape == self.model.density.shape
             self.optimizer.step(out["mog_visibility"])
         else:
             self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
+        self._mark(evs)
+        if evs is not None:
+            self.__dict__.setdefault("_phase_events", []).append(evs)
         if self.schedule is not None:
             self._set_schedule_state(*self.schedule.after_optimizer_step(self.step_id))
         self.step_id += 1

@@ -410,7 +410,7 @@ def run_workload(args, env, workload, steps, warmup, render_frames):
                 batch_for=batch_for, tracer=tracer, dev=dev)
 
 
-def run_drop_in(res, steps=16, warmup=5, optimizer_type="adam"):
+def run_drop_in(res, steps=16, warmup=5, optimizer_type="adam", raw_parameters=True):
     """The SAME workload through the reference's own surface, untouched trainer side: Tracer.render -> Tracer._Autograd ->
     torch loss -> loss.backward() -> torch.optim.Adam (3dgrut_amd/train.TrainStep = trainer.py:705-778 with only the renderer
     swapped).  This is what a user of threedgrut.trainer gets by switching the plugin; `value` above additionally needs the
@@ -420,11 +420,16 @@ def run_drop_in(res, steps=16, warmup=5, optimizer_type="adam"):
     train_mod = importlib.import_module("3dgrut_amd.train")
     dev = res["dev"]
     model = model_mod.GaussianModel(res["scene"], device=dev, sh_degree=3)
+    # Tracer.raw_parameters (default True): a model with the reference's activation callables hands its nn.Parameters over as they
+    # are and the library applies normalize / exp / sigmoid in-kernel (gut_trace_raw_model_fields); False = the reference's own
+    # calls (model.get_rotation() ... as torch kernels, tracer.py:323-327)
+    res["tracer"].raw_parameters = bool(raw_parameters)
     stepper = train_mod.TrainStep(model, res["tracer"], scene_extent=res["extent"], world_size=1, optimizer_type=optimizer_type)
     for s in range(warmup):
         stepper.step(res["batch_for"](s))
     torch.cuda.synchronize(dev)
     res["tracer"].tracer_wrapper.collect_times()
+    stepper.phase_timing = True
     gc.freeze()
     t0 = time.perf_counter()
     for s in range(steps):
@@ -433,12 +438,18 @@ def run_drop_in(res, steps=16, warmup=5, optimizer_type="adam"):
     gc.unfreeze()
     dt = time.perf_counter() - t0
     fb = res["tracer"].tracer_wrapper.collect_times()
+    phases = stepper.phase_times_mean()
+    # where a drop-in step goes: the trainer's four calls, and inside the first and third the plugin's own share
+    phases = {"render_call": phases.get("render"), "of_which_plugin_forward": fb.get("forward_render"), "loss": phases.get("loss"),
+              "backward_call": phases.get("backward"), "of_which_plugin_backward": fb.get("backward_render"), "optimizer_step": phases.get("optimizer")}
+    form = "the model's pre-activation tensors, activated in-kernel (Tracer.raw_parameters)" if raw_parameters else "torch activations (model.get_rotation() ...), as the reference calls them"
     if optimizer_type == "selective_adam":
         return {"trainer": "autograd (Tracer.render -> _Autograd -> SelectiveAdam.step(mog_visibility)): optimizer.type=selective_adam, both plugins swapped",
-                "value": steps / dt, "unit": "images/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps, "warmup": warmup}
+                "parameters": form, "value": steps / dt, "unit": "images/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps, "warmup": warmup,
+                "phase_ms": phases}
     return {"trainer": "autograd (Tracer.render -> _Autograd -> torch.optim.Adam(fused)), the reference's surface unchanged",
-            "value": steps / dt, "unit": "images/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps, "warmup": warmup,
-            "forward_render_ms": fb.get("forward_render"), "backward_render_ms": fb.get("backward_render")}
+            "parameters": form, "value": steps / dt, "unit": "images/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps, "warmup": warmup,
+            "forward_render_ms": fb.get("forward_render"), "backward_render_ms": fb.get("backward_render"), "phase_ms": phases}
 
 
 def main():
@@ -660,6 +671,10 @@ def main():
                 out["drop_in"]["selective_adam"] = run_drop_in(res, optimizer_type="selective_adam")
             except Exception as e:
                 out["drop_in"]["selective_adam"] = {"error": f"{type(e).__name__}: {e}"}
+            try:   # the same with the reference's own activation calls (what `drop_in` was until round 3)
+                out["drop_in"]["torch_activations"] = run_drop_in(res, raw_parameters=False)
+            except Exception as e:
+                out["drop_in"]["torch_activations"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and res.get("colmap"):
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "not run: the CPU legs are wired for the named workloads' orbit cameras, not for --colmap views"}

@@ -34,7 +34,7 @@ extern "C" {
  * 4: gut_trace_model_fields / gut_trace_bwd_model_fields, gut_position_gradient_statistics, gut_set_position_gradient_statistics,
  * gut_mcmc_perturb; 5: behaviour, not layout — GUT_OPT_SORTED_REFERENCE_BACKWARD defaults to 1, the reference's own form of the
  * sorted variant's backward; the UT sigma-point spread is rounded from double like the reference's build script does;
- * GutLazyMoments.d_overrun). */
+ * GutLazyMoments.d_overrun; gut_trace_raw_model_fields; GUT_OPT_FORWARD_TILE_ORDER). */
 #define GUT_ABI_VERSION 5
 
 typedef struct gut_context* gut_handle;
@@ -121,8 +121,10 @@ enum {
     GUT_BUF_GRAD_SCRATCH = 12, /* f32 [N,16] per-Gaussian gradient rows of the last trace_bwd */
     GUT_BUF_TILE_TRAVERSED_FWD = 13, /* u32 [T] list entries each tile walked before all its rays terminated */
     GUT_BUF_TILE_TRAVERSED_BWD = 14, /* u32 [T] same, last trace_bwd */
-    GUT_BUF_ORDERED_IDS = 15   /* u32 [M] what the compositors actually walked: per tile, the ids in final order for the chunks the
+    GUT_BUF_ORDERED_IDS = 15,  /* u32 [M] what the compositors actually walked: per tile, the ids in final order for the chunks the
                                   forward staged (0xFFFFFFFF beyond); equals SORTED_IDS on those positions */
+    GUT_BUF_PACKED_ROWS = 16   /* f32 [N,12] the rows the last gut_trace_fields / _model_fields / _raw_model_fields forward packed (and, for
+                                  the raw entry point, activated: |quat| in the pad column) — what the kernels actually read */
 };
 
 /* fills *cfg with the reference defaults (configs/render/3dgut.yaml + 3dgrt.yaml) */
@@ -211,6 +213,19 @@ int gut_trace_model_fields(gut_handle h, void* stream, uint32_t frame_number, in
                            const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
                            float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
                            float* d_particle_visibility);
+/* gut_trace_model_fields on the model's PRE-ACTIVATION tensors — what MixtureOfGaussians keeps as nn.Parameters (density logit,
+ * un-normalised quaternion, log-scale; threedgrut/model/model.py:74-93 with configs/base_gs.yaml:54-55: sigmoid / exp, rotation
+ * always normalize): the three activations and the row packing run as one kernel, and the gut_trace_bwd_model_fields that follows
+ * on this handle returns the gradients w.r.t. those raw tensors (chained through sigmoid' / normalize' / exp').  For a trainer that
+ * keeps the reference's model and optimiser this removes the model's activation kernels, their backward kernels and the
+ * AccumulateGrad copies from every step (6.2 -> 5.2 ms per step on the 6 M stand-in).  The caller (3dgrut_amd/tracer.py: Tracer.render)
+ * uses it only for a model whose three activation callables ARE torch.sigmoid / torch.nn.functional.normalize / torch.exp. */
+int gut_trace_raw_model_fields(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
+                               const float* d_positions, const float* d_density_logit, const float* d_rotation_raw, const float* d_log_scale,
+                               const float* d_features_albedo, const float* d_features_specular, int32_t width, int32_t height,
+                               const float* d_ray_origin, const float* d_ray_direction, const GutCamera* camera,
+                               float* d_ray_radiance_density, float* d_ray_hit_distance, float* d_ray_hit_count,
+                               float* d_particle_visibility);
 int gut_trace_bwd_model_fields(gut_handle h, void* stream, uint32_t frame_number, int32_t num_active_features, uint32_t num_particles,
                                int32_t width, int32_t height, const float* d_ray_origin, const float* d_ray_direction,
                                const GutCamera* camera, const float* d_ray_radiance_density, const float* d_ray_radiance_density_grad,
@@ -255,6 +270,11 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * depths, 18 / 19 tile launch order / ordered prefix): the buffer moves to a fresh device allocation, contents kept (synchronises
  * the device).  tools/scratch_placement.py uses it to find out whose physical placement the compositing kernels' two speeds
  *  belong to. */
+/* GUT_OPT_FORWARD_TILE_ORDER (default -1; unsorted variant): launch order of the forward compositor's tiles.  1 = longest lists
+ * first (a one-workgroup counting sort of the list lengths in front of it), 0 = image order, -1 = decided by the library from the
+ * share of their lists the last frames walked (longest first above 25 %: then the length of a list says how long its tile will
+ * run; read back with the intersection count, no extra synchronisation).  Results do not depend on it. */
+#define GUT_OPT_FORWARD_TILE_ORDER 4
 #define GUT_OPT_DEBUG_REPLACE_SCRATCH 100
 int gut_set_option(gut_handle h, int32_t option, int32_t value);
 

@@ -598,6 +598,38 @@ def test_lazy_tile_order_is_equivalent(name):
         assert rel_l2(getattr(model, k).grad.cpu().numpy(), g.cpu().numpy()) <= 1e-5, k
 
 
+@pytest.mark.parametrize("name", ["c1_pinhole_128", "fisheye_distorted", "dense_big_splats"])
+def test_forward_tile_launch_order_is_transparent(name):
+    """GUT_OPT_FORWARD_TILE_ORDER: the forward compositor launched longest-lists-first (what the library switches to by itself when
+    the last frames walked more than a quarter of their lists) against image order: same image, same traversal depths, same walked
+    lists, same gradients up to the float-atomic order; and the automatic mode decides from the walked share of the frame before
+    the last (read back with the intersection count)."""
+    mk, kind, W, H, (eye, tgt), kw = CASES[name]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    rgba_grad = np.random.default_rng(3).normal(size=(H, W, 4)).astype(np.float32)
+    model = gut_model(sc, 3)
+    outs = []
+    for mode in (0, 1):
+        tr = gut.Tracer({"render": {}})
+        tr.tracer_wrapper.set_forward_tile_order(mode)
+        model.zero_grad(set_to_none=True)
+        out = tr.render(model, to_batch(view, DEV), train=True, frame_id=0)
+        rg = torch.as_tensor(rgba_grad, device=DEV)
+        ((out["pred_rgb"][0] * rg[..., :3]).sum() + (out["pred_opacity"][0] * rg[..., 3:]).sum()).backward()
+        r = tr.tracer_wrapper
+        outs.append(dict(rgb=out["pred_rgb"].detach().clone(), dist=out["pred_dist"].detach().clone(), hits=out["hits_count"].detach().clone(),
+                         trav=r.debug_buffer("tile_traversed_fwd"), ordered=r.debug_buffer("ordered_ids"),
+                         grads={k: getattr(model, k).grad.clone() for k in ("positions", "rotation", "scale", "density", "features_albedo")}))
+    a, b = outs
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["dist"], b["dist"]) and torch.equal(a["hits"], b["hits"])
+    assert torch.equal(a["trav"], b["trav"]) and torch.equal(a["ordered"], b["ordered"])
+    for k in a["grads"]:
+        assert rel_l2(b["grads"][k].cpu().numpy(), a["grads"][k].cpu().numpy()) <= 1e-5, k
+    with pytest.raises(RuntimeError):
+        gut.Tracer({"render": {}}).tracer_wrapper.set_forward_tile_order(2)
+
+
 def test_forward_queued_before_the_count_is_known_overflow_and_padding():
     """The forward sizes its binning buffers from earlier frames and queues everything before this frame's intersection
     count has been read back (gut_api.cpp).  Frame 1 on a handle has nothing to size from (blocking path); a later frame
@@ -725,6 +757,58 @@ def test_model_field_trace_equals_the_field_wise_trace(n, degree):
     b.trace(0, degree, d12, sph, ro, rd, None, sensor, ts[0], ts[1], ps[0], ps[1])
     with pytest.raises(RuntimeError, match="forward on this handle"):
         b.trace_bwd_model_fields(0, degree, n, ro, rd, sensor, ts[0], ts[1], ps[0], ps[1], out_b[0], g, out_b[1], dg)
+
+
+@pytest.mark.parametrize("case", ["c1_pinhole_128", "fisheye_distorted", "dense_big_splats", "ragged_100x70"])
+def test_raw_parameter_render_against_the_oracle_and_the_activated_render(case):
+    """Tracer.raw_parameters (the product default for a model with the reference's activation callables: the model's PRE-ACTIVATION
+    rotation / scale / density tensors go to gut_trace_raw_model_fields, which applies normalize / exp / sigmoid in-kernel, and the
+    backward returns raw-parameter gradients): (1) the rows the library activated equal torch's own activations to a few ulps;
+    (2) the oracle fed THOSE rows agrees like everywhere else — integer buffers and projection floats bit for bit, image within
+    tolerance; (3) the parameter gradients equal the ones autograd produces through torch's activations (the reference's path) up to
+    the float-atomic order and the ulps of (1)."""
+    mk, kind, W, H, (eye, tgt), kw = CASES[case]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    batch = to_batch(view, DEV)
+    rgba_grad = torch.as_tensor(np.random.default_rng(21).normal(size=(H, W, 4)).astype(np.float32), device=DEV)
+    grads, outs, rasters = {}, {}, {}
+    for raw in (False, True):
+        model = gut_model(sc, 3)
+        tracer = gut.Tracer({"render": {}})
+        tracer.raw_parameters = raw
+        out = tracer.render(model, batch, train=True)
+        ((out["pred_rgb"][0] * rgba_grad[..., :3]).sum() + (out["pred_opacity"][0] * rgba_grad[..., 3:]).sum()).backward()
+        grads[raw] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        outs[raw], rasters[raw] = out, tracer.tracer_wrapper
+        if raw:
+            rows = tracer.tracer_wrapper.debug_buffer("packed_rows").reshape(-1, 12).cpu().numpy()
+            with torch.no_grad():
+                ref_rows = torch.cat([model.positions, model.get_density(), model.get_rotation(), model.get_scale()], 1).cpu().numpy()
+            # (1) in-kernel activation vs torch's: a few ulps (expf / division vs reciprocal-multiply), never more
+            assert np.allclose(rows[:, :11], ref_rows, rtol=4e-7, atol=1e-30), float(np.abs(rows[:, :11] / ref_rows - 1).max())
+            assert np.allclose(rows[:, 11], np.linalg.norm(model.rotation.detach().cpu().numpy(), axis=1), rtol=1e-6)
+            # (2) the oracle on the rows the kernels read (pad column zeroed: the oracle's rows are [pos | dns | quat | scale | 0])
+            d12 = rows.copy(); d12[:, 11] = 0.0
+            sph = model.get_features().detach().cpu().numpy()
+            ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+            r = tracer.tracer_wrapper
+            for key in ("tiles_count", "tiles_offset", "unsorted_ids", "sorted_ids"):
+                assert np.array_equal(r.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
+            assert np.array_equal(r.debug_buffer("sorted_keys").cpu().numpy().view(np.uint64), ref["sorted_keys"])
+            for key in ("proj_pos", "conic_opacity", "extent", "depth", "feat"):
+                got = r.debug_buffer(key).cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)), key
+            margins, pixel_budget = oracle.render_margins(view["oracle_cam"], ref, budget_bound=ROW_FLIP_BOUND)
+            rgba = np.concatenate([out["pred_rgb"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
+            check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"{case}/raw", budget=pixel_budget)
+    # (3) the two paths: same image up to what a few ulps in the inputs do, same gradients w.r.t. the model's parameters
+    assert float((outs[True]["pred_rgb"] - outs[False]["pred_rgb"]).abs().max()) <= 5e-5
+    assert set(grads[True]) == set(grads[False]) and {"rotation", "scale", "density"} <= set(grads[True])
+    for k in grads[False]:
+        a, b = grads[True][k].cpu().numpy(), grads[False][k].cpu().numpy()
+        assert a.shape == b.shape and np.isfinite(a).all(), k
+        assert rel_l2(a, b) <= 2e-4, (k, rel_l2(a, b))
 
 
 @pytest.mark.parametrize("case", ["c1_pinhole_128", "fisheye_144x96"])
