@@ -216,7 +216,7 @@ def self_launch(argv, n_gpus):
 def profile_counters():
     """Per-kernel PMC counters of the tracked profile of this command (profiles/<latest round>/pmc_traffic.json, pmc_sq.json)."""
     out = {}
-    for rnd in ("round3", "round2", "round1"):
+    for rnd in ("round4", "round3", "round2", "round1"):
         d = os.path.join(ROOT, "profiles", rnd)
         if not os.path.isfile(os.path.join(d, "pmc_traffic.json")):
             continue
