@@ -33,6 +33,24 @@
 
 namespace gut {
 
+#ifdef GUT_CLOCK_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/clock_probe.py builds tools/bin/libgut_hip_stamps.so with -DGUT_CLOCK_STAMPS; the product library
+// has none of this): every workgroup of the backward compositor stamps the shader clock (s_memtime, cycles) and the constant
+// 100 MHz counter (s_memrealtime) at its start and end into a buffer no other code reads — delta cycles / delta real time is the
+// clock the chip actually held during the launch (MI355X_MICROARCH.md, "DVFS give-back" item 6).
+__device__ unsigned long long g_clock_stamps[8192][4];
+// ... and thread 0 of every workgroup of the FORWARD compositor adds up the cycles it spent in the phases of its chunk loop:
+// [0] whole workgroup, [1] lazy selection, [2] staging (id + parameter gather, conversion, up to the barrier), [3] walking the
+// chunk (incl. the wait for the slowest wave at the next loop head)
+__device__ unsigned long long g_k6_phases[8192][4];
+__device__ unsigned long long g_k7_phases[8192][4];   // backward: [0] staging, [1] walk, [2] epilogue + flush, [3] whole workgroup
+#define GUT_K6_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define GUT_K6_ADD(slot, a, b) do { if (threadIdx.x == 0) k6_acc[slot] += (b) - (a); } while (0)
+#else
+#define GUT_K6_STAMP(var) do { } while (0)
+#define GUT_K6_ADD(slot, a, b) do { } while (0)
+#endif
+
 // Staged entry of the two unsorted compositors: the thirteen floats every (pixel, entry) test needs sit in the first 13 dwords read
 // per entry (three ds_read_b128 + one ds_read_b32); the scales — needed by a HIT only (hit distance) — follow as one aligned
 // ds_read_b96, the colour and the id as before.  Against FwdEntry's rows [m_i.xyz | s_i] this frees three VGPRs in each of the two
@@ -106,6 +124,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (optional) longest lists first
     const uint32_t tid = threadIdx.x;
+#ifdef GUT_CLOCK_STAMPS
+    unsigned long long k6_acc[4] = {0, 0, 0, 0}, k6_prev = 0;
+#endif
+    GUT_K6_STAMP(k6_t_begin);
     const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + tile_px(tid);   // wave = 8x8 block (gut_render_common.h)
     const int py = (int)(tile / (uint32_t)v.grid_x) * kTile + tile_py(tid);
     const bool inside = (px < v.width) && (py < v.height);
@@ -145,10 +167,19 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
         {
             const uint32_t k = range.x + base + tid;
             uint32_t id = kInvalid;
+#ifdef GUT_CLOCK_STAMPS
+            const unsigned long long k6_tA = __builtin_amdgcn_s_memtime();
+            if (k6_prev) GUT_K6_ADD(3, k6_prev, k6_tA);    // walking the previous chunk + the wait for its slowest wave
+            unsigned long long k6_tB = k6_tA;
+#endif
             if (kLazy) {
                 if (batch_used == batch_n) {  // block-uniform: order the next kLazyBatch entries of the tile
                     batch_n = min(kLazyBatch, total - base);
                     lazy_select(s_lazy, tile_keys + range.x, total, batch_n, have_lo, lo_d, lo_p, tid);
+#ifdef GUT_CLOCK_STAMPS
+                    k6_tB = __builtin_amdgcn_s_memtime();
+                    GUT_K6_ADD(1, k6_tA, k6_tB);
+#endif
                     have_lo = true;
                     lo_d = s_lazy.sel_depth[batch_n - 1];
                     lo_p = s_lazy.sel_pos[batch_n - 1];
@@ -187,6 +218,11 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
             stage[tid] = pack_entry(e);
             s_mask[tid] = strips;
             if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
+#ifdef GUT_CLOCK_STAMPS
+            __syncthreads();
+            k6_prev = __builtin_amdgcn_s_memtime();
+            GUT_K6_ADD(2, k6_tB, k6_prev);
+#endif
         }
         __syncthreads();
 
@@ -298,6 +334,14 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     }
     // traversal statistics (E_f of the roofline model): deepest list position any pixel of the tile consumed (s_deepest)
     __syncthreads();
+#ifdef GUT_CLOCK_STAMPS
+    if (tid == 0 && blockIdx.x < 8192) {
+        const unsigned long long k6_t_end = __builtin_amdgcn_s_memtime();
+        if (k6_prev) k6_acc[3] += k6_t_end - k6_prev;
+        g_k6_phases[blockIdx.x][0] = k6_t_end - k6_t_begin;
+        g_k6_phases[blockIdx.x][1] = k6_acc[1]; g_k6_phases[blockIdx.x][2] = k6_acc[2]; g_k6_phases[blockIdx.x][3] = k6_acc[3];
+    }
+#endif
     if (tid == 0) {
         tile_traversed[tile] = s_deepest;
         if (kLazy) tile_ordered[tile] = min(base, total);  // the backward reads ordered_ids[range.x .. range.x + that) only
@@ -396,14 +440,6 @@ __device__ __forceinline__ uint32_t reduce_slot(uint32_t lane) { return (lane & 
 
 constexpr int kGradRow = 16;  // floats per global gradient row: pos3, density, quat4, scale3, rgb3, pad2
 
-#ifdef GUT_CLOCK_STAMPS
-// DIAGNOSTIC BUILD ONLY (tools/clock_probe.py builds tools/bin/libgut_hip_stamps.so with -DGUT_CLOCK_STAMPS; the product library
-// has none of this): every workgroup of the backward compositor stamps the shader clock (s_memtime, cycles) and the constant
-// 100 MHz counter (s_memrealtime) at its start and end into a buffer no other code reads — delta cycles / delta real time is the
-// clock the chip actually held during the launch (MI355X_MICROARCH.md, "DVFS give-back" item 6).
-__device__ unsigned long long g_clock_stamps[8192][4];
-#endif
-
 // accumulator slots inside a chunk row
 //   0..8  A[i][j] = sum h_i m_j     9..11 H_i = sum h_i     12 d(density)     13..15 d(rgb)     [16..18 direct d(scale)]
 template <bool kDistGrad>
@@ -443,6 +479,7 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
 #ifdef GUT_CLOCK_STAMPS
+    unsigned long long k7_acc[3] = {0, 0, 0};
     if (tid == 0 && blockIdx.x < 8192) {
         g_clock_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime();
         g_clock_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
@@ -501,6 +538,9 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
     constexpr bool kCentred = decltype(centred_tag)::value;
     for (uint32_t base = 0; base < total; base += kBlock) {
         if (!__syncthreads_or(alive ? 1 : 0)) break;
+#ifdef GUT_CLOCK_STAMPS
+        const unsigned long long k7_tA = __builtin_amdgcn_s_memtime();
+#endif
         {
             const uint32_t k = range.x + base + tid;
             uint32_t id = kInvalid;
@@ -531,6 +571,9 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             if (id == kInvalid && k < range.y) atomicMin(&s_first_invalid, tid);
         }
         __syncthreads();
+#ifdef GUT_CLOCK_STAMPS
+        const unsigned long long k7_tB = __builtin_amdgcn_s_memtime();
+#endif
 
         const uint32_t cnt_all = min((uint32_t)kBlock, total - base);
         const uint32_t cnt = min(cnt_all, s_first_invalid);  // padding ids end the list for everyone
@@ -688,6 +731,9 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
         if (cnt < cnt_all) alive = false;  // list ended at a padding entry
         // ---- chunk epilogue: (A, H) -> d(position), d(scale), d(quaternion), one entry per lane ----
         __syncthreads();
+#ifdef GUT_CLOCK_STAMPS
+        const unsigned long long k7_tC = __builtin_amdgcn_s_memtime();
+#endif
         if (tid < cnt) {
             float* a = &acc[tid * W];
             const uint32_t id = __float_as_uint(stage[tid].feat_id.w);
@@ -750,6 +796,12 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             acc[e * W + k] = 0.0f;
             if (kDistGrad && k < 4) acc[e * W + 16 + k] = 0.0f;
         }
+#ifdef GUT_CLOCK_STAMPS
+        if (tid == 0) {   // [0] staging, [1] walking + wait for the slowest wave, [2] epilogue + flush
+            const unsigned long long k7_tD = __builtin_amdgcn_s_memtime();
+            k7_acc[0] += k7_tB - k7_tA; k7_acc[1] += k7_tC - k7_tB; k7_acc[2] += k7_tD - k7_tC;
+        }
+#endif
     }
     };
     if (centred) walk(std::true_type{}); else walk(std::false_type{});
@@ -761,6 +813,8 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
     if (tid == 0 && blockIdx.x < 8192) {
         g_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime();
         g_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+        g_k7_phases[blockIdx.x][0] = k7_acc[0]; g_k7_phases[blockIdx.x][1] = k7_acc[1]; g_k7_phases[blockIdx.x][2] = k7_acc[2];
+        g_k7_phases[blockIdx.x][3] = g_clock_stamps[blockIdx.x][2] - g_clock_stamps[blockIdx.x][0];
     }
 #endif
 }
@@ -829,6 +883,12 @@ __global__ __launch_bounds__(1024) void k_tile_order(uint32_t tiles, const uint3
 // diagnostic build only: copies the backward compositor's clock stamps [8192][4] u64 to the host
 extern "C" int gut_debug_clock_stamps(void* host_dst) {
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gut::g_clock_stamps), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : 1;
+}
+extern "C" int gut_debug_k7_phases(void* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gut::g_k7_phases), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : 1;
+}
+extern "C" int gut_debug_k6_phases(void* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gut::g_k6_phases), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : 1;
 }
 namespace gut {
 #endif

@@ -63,6 +63,20 @@ for w in range(windows):
     # workgroups resident at once, averaged over the launch: sum of the workgroups' lifetimes / span of the launch (100 MHz ticks)
     span = float(stamps[ok, 3].max() - stamps[ok, 1].min())
     resident = rt.sum() / max(span, 1.0) / 256.0
+    if hasattr(lib, "gut_debug_k6_phases"):
+        ph = np.zeros((8192, 4), np.uint64)
+        assert lib.gut_debug_k6_phases(ph.ctypes.data_as(C.c_void_p)) == 0
+        ph = ph[ph[:, 0] > 0].astype(np.float64)
+        tot = ph[:, 0].sum()
+        k6 = f"  K6 workgroup time: select {ph[:, 1].sum() / tot:.2f} stage {ph[:, 2].sum() / tot:.2f} walk {ph[:, 3].sum() / tot:.2f} (mean wg cycles {ph[:, 0].mean():.0f})"
+    else:
+        k6 = ""
+    if hasattr(lib, "gut_debug_k7_phases"):
+        ph = np.zeros((8192, 4), np.uint64)
+        assert lib.gut_debug_k7_phases(ph.ctypes.data_as(C.c_void_p)) == 0
+        ph = ph[ph[:, 3] > 0].astype(np.float64)
+        tot = ph[:, 3].sum()
+        k6 += f"  K7 workgroup time: stage {ph[:, 0].sum() / tot:.2f} walk {ph[:, 1].sum() / tot:.2f} epilogue+flush {ph[:, 2].sum() / tot:.2f}"
     print(f"{w:3d}  K6 {t['render']:.3f}  K7 {t['render_bwd']:.3f}  clock {np.median(ghz):.3f} / {np.quantile(ghz, 0.1):.3f} / {np.quantile(ghz, 0.9):.3f} GHz  "
           f"wg cycles median {np.median(cyc):.0f} mean {cyc.mean():.0f}  K7 x GHz {t['render_bwd'] * np.median(ghz):.3f}  resident per CU {resident:.2f}  "
-          f"stamped span {span * 1e-5:.3f} ms", flush=True)
+          f"stamped span {span * 1e-5:.3f} ms{k6}", flush=True)
