@@ -19,6 +19,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 UNITS = [
     ("gut_project.hip", ["-ffp-contract=off"]),
     ("gut_render.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"]),
+    ("gut_render_general.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"]),
     ("gut_render_sorted.hip", ["-ffp-contract=fast", "-munsafe-fp-atomics", "-fno-slp-vectorize"]),
     ("gut_sort.hip", ["-Wno-unused-parameter"]),
     ("gut_ssim.hip", ["-ffp-contract=fast"]),
@@ -54,7 +55,7 @@ def build_diagnostic(out, defines, verbose=False):
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "gut_internal.h"), os.path.join(CSRC, "gut_render_common.h"),
+    headers = [os.path.join(CSRC, "gut_internal.h"), os.path.join(CSRC, "gut_render_common.h"), os.path.join(CSRC, "gut_render.hip"),
                os.path.join(HERE, "..", "include", "gut_hip.h")]
     objs = []
     for src, extra in UNITS:

@@ -214,7 +214,7 @@ struct gut_context {
 
 namespace {
 
-int build_view(const GutCamera* cam, int W, int H, gut::ViewParams* v) {
+int build_view(const GutCamera* cam, int W, int H, int shutter_iterations, gut::ViewParams* v) {
     if (cam->model != GUT_CAMERA_OPENCV_PINHOLE && cam->model != GUT_CAMERA_OPENCV_FISHEYE)
         return fail("unsupported camera model %d (only OpenCV pinhole / fisheye exist in the reference)", cam->model);
     if (cam->shutter < GUT_SHUTTER_ROLLING_TOP_TO_BOTTOM || cam->shutter > GUT_SHUTTER_GLOBAL)
@@ -256,6 +256,7 @@ int build_view(const GutCamera* cam, int W, int H, gut::ViewParams* v) {
     for (int i = 0; i < 6; ++i) v->radial[i] = cam->radial_coeffs[i];
     for (int i = 0; i < 4; ++i) v->thin_prism[i] = cam->thin_prism_coeffs[i];
     v->max_angle = cam->max_angle;
+    v->shutter_iterations = shutter_iterations;
     return 0;
 }
 
@@ -278,7 +279,9 @@ void build_consts(const GutConfig& cfg, gut::RenderConsts* c) {
     c->tight_opacity_bounding = cfg.tight_opacity_bounding;
     c->tile_culling = cfg.tile_based_culling;
     c->global_z_order = cfg.global_z_order;
-    c->max_d2 = -2.0f * logf(cfg.particle_kernel_min_response);
+    // the early-out radius of the compositors; the exact response / alpha tests follow it, so a small margin is free
+    c->max_d2 = cfg.particle_kernel_degree == 2 ? -2.0f * logf(cfg.particle_kernel_min_response)
+                                                : gut::kernel_cutoff_d2(cfg.particle_kernel_degree, cfg.particle_kernel_min_response) * 1.0001f + 1e-6f;
 }
 
 EventPair* arm_timer(std::deque<EventPair>& q, hipStream_t s) {
@@ -353,13 +356,16 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
     if (cfg->abi_version != GUT_ABI_VERSION) return fail("gut_create: ABI version %d, library is %d", cfg->abi_version, GUT_ABI_VERSION);
     // the reference compiles one kernel variant per render config (setup_3dgut.py:47-70); this library ships
     // the default 3dgut variant and says so instead of silently rendering something else
-    if (cfg->particle_kernel_degree != 2) return fail("particle_kernel_degree=%d: only the quadratic (2) kernel of render/3dgut.yaml is built", cfg->particle_kernel_degree);
+    switch (cfg->particle_kernel_degree) {   // particleResponse<> has exactly these cases (gaussianParticles.cuh:256-306; anything else
+    case 0: case 1: case 2: case 3: case 4: case 5: case 8: break;   // falls to its quadratic default, which would be a silent surprise)
+    default: return fail("particle_kernel_degree=%d: the reference's generalised Gaussian kernels are 0, 1, 2, 3, 4, 5 and 8", cfg->particle_kernel_degree);
+    }
     if (cfg->k_buffer_size < 0 || cfg->k_buffer_size > 16)
         return fail("k_buffer_size=%d: supported range is 0 (unsorted) .. 16", cfg->k_buffer_size);
     if (cfg->particle_radiance_sph_degree != 3) return fail("particle_radiance_sph_degree=%d: only degree 3 (16 coefficients) is built", cfg->particle_radiance_sph_degree);
     if (cfg->ut_require_all_sigma_points != 0) return fail("ut_require_all_sigma_points must be false (static_assert in threedgut.cuh:73)");
-    if (!cfg->enable_hitcounts) return fail("enable_hitcounts=false is not built");
-    if (cfg->n_rolling_shutter_iterations != 5) return fail("n_rolling_shutter_iterations=%d: only 5 (render/3dgut.yaml) is built", cfg->n_rolling_shutter_iterations);
+    if (cfg->n_rolling_shutter_iterations < 0 || cfg->n_rolling_shutter_iterations > 64)
+        return fail("n_rolling_shutter_iterations=%d outside 0..64", cfg->n_rolling_shutter_iterations);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_index < 0 || device_index >= ndev) return fail("gut_create: device %d out of range (%d devices)", device_index, ndev);
@@ -451,7 +457,7 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
     gut::ViewParams v;
-    if (build_view(camera, width, height, &v)) return 1;
+    if (build_view(camera, width, height, h->cfg.n_rolling_shutter_iterations, &v)) return 1;
     const uint32_t n = num_particles;
     const int tiles = v.grid_x * v.grid_y;
     if ((uint64_t)tiles >= 0xFFFFFFFFull) return fail("gut_trace: too many tiles");
@@ -578,7 +584,7 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
             HIP_TRY(hipMemsetAsync(h->trav_fwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
             gut::launch_render_sorted(s, v, h->consts, h->cfg.k_buffer_size, d_particle_density, h->feat.as<float>(), d_ray_origin,
                                       d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(), d_count,
-                                      d_ray_radiance_density, d_ray_hit_distance, d_ray_hit_count);
+                                      d_ray_radiance_density, d_ray_hit_distance, d_ray_hit_count, h->cfg.particle_kernel_degree);
         } else {
             // Longest lists first (as the backward launches its deepest tiles first), when the frames before this one walked a good part
             // of their lists — then a tile's list length says how long it will run, and the few long ones must not form the tail of
@@ -594,8 +600,11 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
                                d_ray_hit_distance, d_ray_hit_count, h->trav_fwd.as<uint32_t>(),
                                lazy ? h->keys_sorted.as<uint64_t>() : nullptr, lazy ? h->ids_ordered.as<uint32_t>() : nullptr,
                                lazy ? h->tile_ordered.as<uint32_t>() : nullptr,
-                               (fwd_order && sort_n) ? h->tile_order.as<uint32_t>() : nullptr);
+                               (fwd_order && sort_n) ? h->tile_order.as<uint32_t>() : nullptr, h->cfg.particle_kernel_degree);
         }
+        // render.enable_hitcounts = false: the reference compiles the counter out (rayPayload.cuh:44-46,69-73,126-128) and its
+        // output tensor keeps the zeros it was created with (splatRaster.cpp:198).  Not a configuration worth a kernel variant.
+        if (!h->cfg.enable_hitcounts) HIP_TRY(hipMemsetAsync(d_ray_hit_count, 0, sizeof(float) * (size_t)width * (size_t)height, s));
         return 0;
     };
     // the k-buffer variant walks whole lists: it keeps the full sort
@@ -871,7 +880,7 @@ static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
     gut::ViewParams v;
-    if (build_view(camera, width, height, &v)) return 1;
+    if (build_view(camera, width, height, h->cfg.n_rolling_shutter_iterations, &v)) return 1;
     if (memcmp(&v, &h->view, sizeof(v)) != 0) return fail("gut_trace_bwd: camera differs from the cached forward");
     const uint32_t n = h->n;
     if (n == 0) return 0;
@@ -900,7 +909,7 @@ static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
         gut::launch_render_sorted_bwd(s, v, h->consts, h->cfg.k_buffer_size, d_particle_density, h->feat.as<float>(), d_ray_origin,
                                       d_ray_direction, h->ranges.as<uint32_t>(), h->ids_sorted.as<uint32_t>(),
                                       d_ray_radiance_density, d_ray_hit_distance, d_ray_radiance_density_grad,
-                                      d_ray_hit_distance_grad, h->grad16.as<float>(), h->sorted_reference_bwd);
+                                      d_ray_hit_distance_grad, h->grad16.as<float>(), h->sorted_reference_bwd, h->cfg.particle_kernel_degree);
     } else if (h->m) {
         HIP_TRY(h->walk_sums.ensure(2 * sizeof(uint32_t)));
         gut::launch_tile_order(s, (uint32_t)h->tiles, h->trav_fwd.as<uint32_t>(), h->tile_order.as<uint32_t>(), h->ranges.as<uint32_t>(), false,
@@ -909,7 +918,7 @@ static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
                                h->ranges.as<uint32_t>(), (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(),
                                d_ray_radiance_density,
                                d_ray_radiance_density_grad, d_ray_hit_distance_grad, h->grad16.as<float>(),
-                               h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>(), h->trav_fwd.as<uint32_t>());
+                               h->trav_bwd.as<uint32_t>(), h->tile_order.as<uint32_t>(), h->trav_fwd.as<uint32_t>(), h->cfg.particle_kernel_degree);
     }
     mark(10);
     if (flags & GUT_BWD_SKIP_EPILOGUE) {

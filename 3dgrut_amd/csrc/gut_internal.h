@@ -1,6 +1,7 @@
 // gut_internal.h — types shared by the HIP translation units of libgut_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/gut_hip.h"
@@ -34,6 +35,7 @@ struct ViewParams {
     float tangential[2];
     float thin_prism[4];
     float max_angle;
+    int32_t shutter_iterations;   // GAUSSIAN_N_ROLLING_SHUTTER_ITERATIONS (threedgut.cuh:63), rolling shutters only
 };
 
 // Derived render constants (host-computed in fp32 with the same operation order as the oracle).
@@ -42,8 +44,23 @@ struct RenderConsts {
     float min_sensor_z, cov_dilation;
     float ut_delta, ut_w0_mean, ut_wi, ut_w0_cov, ut_margin;
     int32_t rect_bounding, tight_opacity_bounding, tile_culling, global_z_order;
-    float max_d2;   // -2 ln(min_response): d2 above this can never be accepted
+    float max_d2;   // -2 ln(min_response): d2 above this can never be accepted (kernel degree 2; kernel_cutoff_d2 otherwise)
 };
+
+// largest d2 at which the kernel's response still reaches r (0 < r < 1), without safety margin
+__host__ __device__ inline float kernel_cutoff_d2(int degree, float r) {
+    float s, n;
+    switch (degree) {
+    case 8: s = 0.000685871056241f; n = 8.0f; break;
+    case 5: s = 0.0185185185185f; n = 5.0f; break;
+    case 4: s = 0.0555555555556f; n = 4.0f; break;
+    case 3: s = 0.166666666667f; n = 3.0f; break;
+    case 1: s = 1.5f; n = 1.0f; break;
+    case 0: { const float t = (1.0f - r) / 0.329630334487f; return t * t; }
+    default: return -2.0f * logf(r);
+    }
+    return powf(-logf(r) / s, 2.0f / n);
+}
 
 // device-side counters (one 64-byte line)
 struct Counters {
@@ -103,22 +120,34 @@ void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, co
                    const uint32_t* sorted_ids, const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits,
                    uint32_t* tile_traversed, const uint64_t* tile_keys /* lazy order only */, uint32_t* ordered_ids /* NULL = list is fully sorted */,
                    uint32_t* tile_ordered /* lazy order: entries of each tile's list written to ordered_ids */,
-                   const uint32_t* tile_order = nullptr /* launch order of the tiles (longest lists first) or NULL */);
+                   const uint32_t* tile_order = nullptr /* launch order of the tiles (longest lists first) or NULL */,
+                   int kernel_degree = 2 /* render.particle_kernel_degree; != 2 runs the kGeneral instantiation */);
 void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
                        float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order,
-                       const uint32_t* tile_walked /* forward's per-tile traversal depth: the backward stops there */);
+                       const uint32_t* tile_walked /* forward's per-tile traversal depth: the backward stops there */,
+                       int kernel_degree = 2);
+// the same two launches for render.particle_kernel_degree != 2 (gut_render_general.hip; reached through launch_render / launch_render_bwd)
+void launch_render_general(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
+                           const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
+                           const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed,
+                           const uint64_t* tile_keys, uint32_t* ordered_ids, uint32_t* tile_ordered, const uint32_t* tile_order,
+                           int kernel_degree);
+void launch_render_bwd_general(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
+                               const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
+                               const float* rgba, const float* rgba_grad, const float* dist_grad, float* grad16,
+                               uint32_t* tile_traversed, const uint32_t* tile_order, const uint32_t* tile_walked, int kernel_degree);
 void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed, uint32_t* order, const uint32_t* ranges = nullptr,
                        bool by_length = false, uint32_t* walk_sums = nullptr);
 // sorted (k_buffer_size > 0) compositor variant, gut_render_sorted.hip
 void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
                           const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                          const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits);
+                          const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits, int kernel_degree = 2);
 void launch_render_sorted_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12,
                               const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                               const uint32_t* sorted_ids, const float* rgba, const float* dist, const float* rgba_grad,
-                              const float* dist_grad, float* grad16, bool reference_undo);
+                              const float* dist_grad, float* grad16, bool reference_undo, int kernel_degree = 2);
 void launch_project_bwd_compact(hipStream_t s, uint32_t n, const float* density12, const uint32_t* tiles_count,
                                 const float* feat, float* grad16 /* rows read are left zero */, float* raw_grad12, float* mrgb);
 // fused per-Gaussian backward epilogue + SH-gradient + Adam (gut_train.hip), single view, reads the handle's gradient rows

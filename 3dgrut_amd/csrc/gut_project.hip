@@ -209,7 +209,7 @@ __device__ void shutter_pose_transform(const ViewParams& v, float a, float wx, f
     cz = r20 * wx + r21 * wy + r22 * wz + t2;
 }
 
-// projectPointWithShutter<5> (cameraProjections.cuh:146-185)
+// projectPointWithShutter<N> (cameraProjections.cuh:146-185), N = render.splat.n_rolling_shutter_iterations (5 by default)
 template <int kVariant, bool kRolling>
 __device__ __forceinline__ int project_world(const ViewParams& v, float wx, float wy, float wz, float tol, float& ox,
                                              float& oy) {
@@ -227,7 +227,7 @@ __device__ __forceinline__ int project_world(const ViewParams& v, float wx, floa
         valid = project_camera<kVariant>(v, cx, cy, cz, tol, ox, oy);
         if (!valid) return 0;
     }
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < v.shutter_iterations; ++it) {
         const float al = relative_shutter_time(v, ox, oy);
         shutter_pose_transform(v, al, wx, wy, wz, cx, cy, cz);
         valid = project_camera<kVariant>(v, cx, cy, cz, tol, ox, oy);

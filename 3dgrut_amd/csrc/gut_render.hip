@@ -33,6 +33,21 @@
 
 namespace gut {
 
+// This file is compiled twice: as itself — the default quadratic kernel, `kGeneral` = false everywhere — and through
+// gut_render_general.hip (GUT_RENDER_GENERAL_TU), which instantiates the same kernels with kGeneral = true for the reference's other
+// generalised Gaussian kernels (render.particle_kernel_degree = 0, 1, 3, 4, 5, 8) under the launcher names *_general.  Two translation
+// units, not four instantiations in one: with the extra callers in the unit the inliner stops inlining helpers into the DEFAULT
+// forward compositor (31 -> 102 spilled VGPRs, 64 -> 192 bytes of scratch per lane, measured on the kernel-resource remarks).
+#ifdef GUT_RENDER_GENERAL_TU
+constexpr bool kTuGeneral = true;
+#define GUT_LAUNCH_RENDER launch_render_general
+#define GUT_LAUNCH_RENDER_BWD launch_render_bwd_general
+#else
+constexpr bool kTuGeneral = false;
+#define GUT_LAUNCH_RENDER launch_render
+#define GUT_LAUNCH_RENDER_BWD launch_render_bwd
+#endif
+
 #ifdef GUT_CLOCK_STAMPS
 // DIAGNOSTIC BUILD ONLY (tools/clock_probe.py builds tools/bin/libgut_hip_stamps.so with -DGUT_CLOCK_STAMPS; the product library
 // has none of this): every workgroup of the backward compositor stamps the shader clock (s_memtime, cycles) and the constant
@@ -105,7 +120,8 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 // (5 waves per SIMD: at the 103 VGPRs the compiler takes otherwise the kernel runs 7 % slower, at 6 it spills)
 // kLazy: sorted_ids / tile_keys are only grouped by tile; the kernel orders each chunk itself (lazy_select) and records the
 // ids it consumed in ordered_ids for the backward.
-template <bool kLazy>
+// kGeneral: render.particle_kernel_degree != 2 — the response comes from kernel_response(kernel_degree, .) (gut_render_common.h).
+template <bool kLazy, bool kGeneral = false>
 __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts c, const float4* __restrict__ density12,
                                                      const float* __restrict__ feat, const float* __restrict__ ray_ori,
                                                      const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
@@ -114,7 +130,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                                                      float4* __restrict__ rgba, float* __restrict__ dist,
                                                      float* __restrict__ hits, uint32_t* __restrict__ tile_traversed,
                                                      const uint2* __restrict__ tile_keys, uint32_t* __restrict__ ordered_ids,
-                                                     uint32_t* __restrict__ tile_ordered, const uint32_t* __restrict__ tile_order) {
+                                                     uint32_t* __restrict__ tile_ordered, const uint32_t* __restrict__ tile_order,
+                                                     int kernel_degree /* read by kGeneral only */) {
     __shared__ PackEntry stage[kBlock];
     __shared__ uint32_t s_deepest, s_first_invalid;
     __shared__ uint32_t s_mask[kBlock];  // per staged entry: which of the four waves (8x8 blocks) can hit it at all
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                 e.feat_id.x = fmaxf(feat[3 * (size_t)id + 0], 0.0f);
                 e.feat_id.y = fmaxf(feat[3 * (size_t)id + 1], 0.0f);
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
-                strips = strip_mask(s_planes, v, c, a, r, s);
+                strips = strip_mask<kGeneral>(s_planes, v, c, a, r, s, kernel_degree);
             }
             stage[tid] = pack_entry(e);
             s_mask[tid] = strips;
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
                 const float il2 = fast_rcp(l2);
                 const float d2 = (x0 * x0 + x1 * x1 + x2 * x2) * il2;  // |grd x gro|^2 with grd = u/|u|
                 if (d2 < c.max_d2) {
-                    const float resp = fast_exp(-0.5f * d2);
+                    const float resp = kGeneral ? kernel_response(kernel_degree, d2) : fast_exp(-0.5f * d2);
                     const float alpha = fminf(c.max_alpha, resp * cs.w);
                     if ((resp > c.min_response) && (alpha > c.alpha_threshold)) {
                         // hitT = | s * grd * (grd . -gro) |
@@ -447,7 +464,7 @@ struct AccLayout {
     static constexpr int kW = kDistGrad ? 20 : 16;
 };
 
-template <bool kDistGrad>
+template <bool kDistGrad, bool kGeneral = false>
 __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(ViewParams v, RenderConsts c,
                                                            const float4* __restrict__ density12,
                                                            const float* __restrict__ feat,
@@ -460,7 +477,8 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
                                                            const float* __restrict__ dist_grad, float* __restrict__ grad16,
                                                            uint32_t* __restrict__ tile_traversed,
                                                            const uint32_t* __restrict__ tile_order,
-                                                           const uint32_t* __restrict__ tile_walked) {
+                                                           const uint32_t* __restrict__ tile_walked,
+                                                           int kernel_degree /* read by kGeneral only */) {
     constexpr int W = AccLayout<kDistGrad>::kW;
     __shared__ PackEntry stage[kBlock];
     __shared__ float acc[kBlock * W];
@@ -564,7 +582,7 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
                 e.feat_id.x = fmaxf(feat[3 * (size_t)id + 0], 0.0f);
                 e.feat_id.y = fmaxf(feat[3 * (size_t)id + 1], 0.0f);
                 e.feat_id.z = fmaxf(feat[3 * (size_t)id + 2], 0.0f);
-                strips = strip_mask(s_planes, v, c, a, r, sc);
+                strips = strip_mask<kGeneral>(s_planes, v, c, a, r, sc, kernel_degree);
             }
             stage[tid] = pack_entry(e);
             s_mask[tid] = strips;
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             const float l2 = u0 * u0 + u1 * u1 + u2 * u2;
             const float il2 = fast_rcp(l2);
             const float d2 = (c0 * c0 + c1 * c1 + c2 * c2) * il2;
-            const float resp = fast_exp(-0.5f * d2);
+            const float resp = kGeneral ? kernel_response(kernel_degree, d2) : fast_exp(-0.5f * d2);
             const float a0 = resp * ms.w;
             const float alpha = fminf(c.max_alpha, a0);
             // NB: no tmin/tmax test in the backward
@@ -644,7 +662,8 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             const float Gall = ga_hit + ga_dns + T * ((fid.x - e0) * gr + (fid.y - e1) * gg + (fid.z - e2) * gb);
             const float G = hit ? Gall : 0.0f;
             g[12] = rm * G;                            // d density
-            const float g_d2x2 = -(rm * ms.w) * G;     // 2 * dL/d(d2) = 2 * (-1/2 resp sigma G)
+            const float g_d2x2 = kGeneral ? 2.0f * kernel_response_grad(kernel_degree, d2, rm, ms.w * G)
+                                          : -(rm * ms.w) * G;     // 2 * dL/d(d2) = 2 * (-1/2 resp sigma G)
             float h0 = g_d2x2 * q0, h1 = g_d2x2 * q1, h2 = g_d2x2 * q2;  // dL/do
             if (!kDistGrad) {
                 // m = (ray_o - mu) - t d = (e - t d) + (sensor_pos - mu); the second, per-entry constant part is
@@ -820,19 +839,28 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
 }
 
 // ---------------------------------------------------------------------------------------------------
-void launch_render(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
+void GUT_LAUNCH_RENDER(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12, const float* feat,
                    const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
                    const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits, uint32_t* tile_traversed,
-                   const uint64_t* tile_keys, uint32_t* ordered_ids, uint32_t* tile_ordered, const uint32_t* tile_order) {
+                   const uint64_t* tile_keys, uint32_t* ordered_ids, uint32_t* tile_ordered, const uint32_t* tile_order,
+                   int kernel_degree) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
-    auto kern = ordered_ids != nullptr ? k_render<true> : k_render<false>;
+#ifndef GUT_RENDER_GENERAL_TU
+    if (kernel_degree != 2) {
+        launch_render_general(s, v, c, density12, feat, ray_ori, ray_dir, ranges, sorted_ids, d_num_intersections, rgba, dist, hits,
+                              tile_traversed, tile_keys, ordered_ids, tile_ordered, tile_order, kernel_degree);
+        return;
+    }
+#endif
+    auto kern = ordered_ids != nullptr ? k_render<true, kTuGeneral> : k_render<false, kTuGeneral>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12), feat,
                        ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, d_num_intersections,
                        reinterpret_cast<float4*>(rgba), dist, hits, tile_traversed, reinterpret_cast<const uint2*>(tile_keys),
-                       ordered_ids, tile_ordered, tile_order);
+                       ordered_ids, tile_ordered, tile_order, kernel_degree);
 }
 
+#ifndef GUT_RENDER_GENERAL_TU
 // Launch order for the backward: tiles by decreasing forward traversal depth (the backward walks exactly as deep),
 // longest-processing-time-first, so the few deep tiles do not become the tail of the grid.  One workgroup: 256
 // linear buckets between 0 and the deepest tile, counting sort in LDS; the order inside a bucket is irrelevant.
@@ -899,18 +927,27 @@ void launch_tile_order(hipStream_t s, uint32_t tiles, const uint32_t* traversed,
     hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, tiles, traversed, order, reinterpret_cast<const uint2*>(ranges), by_length,
                        ranges ? walk_sums : nullptr);
 }
+#endif  // !GUT_RENDER_GENERAL_TU
 
-void launch_render_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
+void GUT_LAUNCH_RENDER_BWD(hipStream_t s, const ViewParams& v, const RenderConsts& c, const float* density12,
                        const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                        const uint32_t* sorted_ids, const float* rgba, const float* rgba_grad, const float* dist_grad,
-                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order, const uint32_t* tile_walked) {
+                       float* grad16, uint32_t* tile_traversed, const uint32_t* tile_order, const uint32_t* tile_walked,
+                       int kernel_degree) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
-    auto kern = dist_grad != nullptr ? k_render_backward<true> : k_render_backward<false>;
+#ifndef GUT_RENDER_GENERAL_TU
+    if (kernel_degree != 2) {
+        launch_render_bwd_general(s, v, c, density12, feat, ray_ori, ray_dir, ranges, sorted_ids, rgba, rgba_grad, dist_grad, grad16,
+                                  tile_traversed, tile_order, tile_walked, kernel_degree);
+        return;
+    }
+#endif
+    auto kern = dist_grad != nullptr ? k_render_backward<true, kTuGeneral> : k_render_backward<false, kTuGeneral>;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kBlock), 0, s, v, c, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
                        reinterpret_cast<const float4*>(rgba), reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
-                       tile_traversed, tile_order, tile_walked);
+                       tile_traversed, tile_order, tile_walked, kernel_degree);
 }
 
 }  // namespace gut

@@ -10,6 +10,36 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, ~1 ulp
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
+// ---- generalised Gaussian kernels (render.particle_kernel_degree != 2) ----------------------------------------------------
+// particleResponse<n> / particleResponseGrd<n> of gaussianParticles.cuh:211-306: resp = exp(s_n d2^(n/2)), s_n = -4.5 / 3^n
+// (n = 0: the linear hat max(1 + s sqrt(d2), 0)).  The degree is a kernel ARGUMENT here (block-uniform scalar branch) and only
+// the `kGeneral` instantiations of the compositors look at it: the default quadratic path is compiled exactly as before.
+__device__ __forceinline__ float kernel_response(int degree, float d2) {
+    switch (degree) {
+    case 8: { const float q = d2 * d2; return fast_exp(-0.000685871056241f * (q * q)); }
+    case 5: return fast_exp(-0.0185185185185f * (d2 * d2 * fast_sqrt(d2)));
+    case 4: return fast_exp(-0.0555555555556f * (d2 * d2));
+    case 3: return fast_exp(-0.166666666667f * (d2 * fast_sqrt(d2)));
+    case 1: return fast_exp(-1.5f * fast_sqrt(d2));
+    case 0: return fmaxf(1.0f + -0.329630334487f * fast_sqrt(d2), 0.0f);
+    default: return fast_exp(-0.5f * d2);
+    }
+}
+// dL/d(d2) from dL/d(resp), as the reference writes it — including its degree-1 form, which multiplies by sqrt(d2) where the
+// derivative of exp(s sqrt(d2)) divides by it (gaussianParticles.cuh:248-252): restated, not corrected.  That is the CUDA backward of
+// the unsorted compositor (processHitBwd); the sorted variant is differentiated by slang autodiff from the forward expression
+// (slang/models/gaussianParticles.slang:119-164) and gets the true derivative: as_written = false.
+__device__ __forceinline__ float kernel_response_grad(int degree, float d2, float resp, float g_resp, bool as_written = true) {
+    switch (degree) {
+    case 8: return (float)(-0.000685871056241 * 4.0) * (d2 * d2) * d2 * resp * g_resp;
+    case 5: return (float)(-0.0185185185185 * 2.5) * d2 * fast_sqrt(d2) * resp * g_resp;
+    case 4: return (float)(-0.0555555555556 * 2.0) * d2 * resp * g_resp;
+    case 3: return (float)(-0.166666666667 * 1.5) * fast_sqrt(d2) * resp * g_resp;
+    case 1: return (-1.5f * 0.5f) * (as_written ? fast_sqrt(d2) : fast_rsq(d2)) * resp * g_resp;
+    case 0: return resp > 0.0f ? (0.5f * -0.329630334487f * fast_rsq(d2)) * g_resp : 0.0f;
+    default: return -0.5f * resp * g_resp;
+    }
+}
 struct RayState {
     float ox, oy, oz, dx, dy, dz, tmin, tmax;
     float ex, ey, ez;  // ray origin minus the sensor position (all zero for pinhole / fisheye rays)
@@ -186,12 +216,14 @@ __device__ __forceinline__ void build_strip_planes(StripPlanes& sp, const RaySta
 }
 
 // bit w set <=> wave w has to evaluate the entry.  a = (mean, density), r = rows of rotationT, s = scale
+template <bool kGeneral = false>
 __device__ __forceinline__ uint32_t strip_mask(const StripPlanes& sp, const ViewParams& v, const RenderConsts& c, const float4& a,
-                                               const float (&r)[3][3], const float4& s) {
+                                               const float (&r)[3][3], const float4& s, int kernel_degree = 2) {
     if (sp.usable == 0u) return 0xFu;
     const float ratio = a.w / c.alpha_threshold;  // alpha = resp * density > threshold  <=>  d2 < 2 ln(density / threshold)
     if (!(ratio > 1.0f)) return 0u;               // cannot be hit at all (K1 culls these already)
-    const float D = fminf(c.max_d2, 2.0f * __logf(ratio)) * 1.001f + 1e-3f;
+    const float D = (!kGeneral ? fminf(c.max_d2, 2.0f * __logf(ratio))
+                               : kernel_cutoff_d2(kernel_degree, fmaxf(c.min_response, 1.0f / ratio))) * 1.001f + 1e-3f;
     const float m0 = a.x - v.s2w.t[0], m1 = a.y - v.s2w.t[1], m2 = a.z - v.s2w.t[2];
     uint32_t mask = 0u;
 #pragma unroll

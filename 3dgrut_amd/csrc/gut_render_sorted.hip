@@ -69,7 +69,7 @@ __device__ __forceinline__ void kb_insert(KBuffer& kb, int first, float t, float
 }
 
 // response of a staged entry for this lane's ray; returns accept (response / alpha / range tests of the forward)
-__device__ __forceinline__ bool eval_entry(const RenderConsts& c, const RayState& ray, bool centred, const FwdEntry& e,
+__device__ __forceinline__ bool eval_entry(const RenderConsts& c, int kernel_degree, const RayState& ray, bool centred, const FwdEntry& e,
                                            float& alpha, float& hit_t) {
     float o0 = e.mu_sigma.x, o1 = e.mu_sigma.y, o2 = e.mu_sigma.z;
     if (!centred) {
@@ -85,7 +85,7 @@ __device__ __forceinline__ bool eval_entry(const RenderConsts& c, const RayState
     const float il2 = fast_rcp(l2);
     const float d2 = (x0 * x0 + x1 * x1 + x2 * x2) * il2;
     if (!(d2 < c.max_d2)) return false;
-    const float resp = fast_exp(-0.5f * d2);
+    const float resp = kernel_response(kernel_degree, d2);
     alpha = fminf(c.max_alpha, resp * e.mu_sigma.w);
     if (!((resp > c.min_response) && (alpha > c.alpha_threshold))) return false;
     const float proj = -(u0 * o0 + u1 * o1 + u2 * o2) * il2;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted(ViewParams v, RenderCo
                                                          const float* __restrict__ ray_dir, const uint2* __restrict__ ranges,
                                                          const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ d_num_intersections,
                                                          float4* __restrict__ rgba, float* __restrict__ dist,
-                                                         float* __restrict__ hits) {
+                                                         float* __restrict__ hits, int kernel_degree) {
     __shared__ FwdEntry stage[kBlock];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + (int)(tid & 15);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted(ViewParams v, RenderCo
                 break;
             }
             float a = 0.f, t = 0.f;
-            if (alive && eval_entry(c, ray, centred, e, a, t)) {
+            if (alive && eval_entry(c, kernel_degree, ray, centred, e, a, t)) {
                 if (kb.num == K) {
                     float ft, fa; uint32_t fi;
                     kb_front(kb, first, ft, fa, fi);
@@ -196,7 +196,7 @@ struct PixelGrad {
 };
 
 // exact derivatives of one composited hit w.r.t. the particle's parameters; 14 atomics into its gradient row
-__device__ void backward_hit(const ViewParams& v, const RenderConsts& c, const RayState& ray, const float4* __restrict__ density12,
+__device__ void backward_hit(const ViewParams& v, const RenderConsts& c, int kernel_degree, const RayState& ray, const float4* __restrict__ density12,
                              const float* __restrict__ feat, float* __restrict__ grad16, uint32_t id, float alpha, float hit_t,
                              PixelGrad& pg) {
     const float4 mu = density12[3 * (size_t)id + 0];
@@ -220,7 +220,7 @@ __device__ void backward_hit(const ViewParams& v, const RenderConsts& c, const R
     const float t = uo * il2;
     const float op[3] = {o[0] - t * u[0], o[1] - t * u[1], o[2] - t * u[2]};  // o_perp
     const float d2 = op[0] * op[0] + op[1] * op[1] + op[2] * op[2];          // == |u x o|^2 / |u|^2
-    const float resp = fast_exp(-0.5f * d2);
+    const float resp = kernel_response(kernel_degree, d2);
     const float a0 = resp * mu.w;
 
     const float f[3] = {fmaxf(feat[3 * (size_t)id + 0], 0.0f), fmaxf(feat[3 * (size_t)id + 1], 0.0f),
@@ -265,7 +265,7 @@ __device__ void backward_hit(const ViewParams& v, const RenderConsts& c, const R
     // alpha = min(max_alpha, sigma * resp): zero derivative where clamped
     const bool clamped = a0 >= c.max_alpha;
     out[3] = clamped ? 0.0f : resp * g_alpha;
-    const float g_d2x2 = clamped ? 0.0f : -a0 * g_alpha;  // 2 dL/d(d2)
+    const float g_d2x2 = clamped ? 0.0f : 2.0f * kernel_response_grad(kernel_degree, d2, resp, mu.w * g_alpha, false);  // 2 dL/d(d2)
     float go[3] = {g_d2x2 * op[0], g_d2x2 * op[1], g_d2x2 * op[2]};
     float gu[3] = {-t * go[0], -t * go[1], -t * go[2]};
     float gs_direct[3] = {0.f, 0.f, 0.f};
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted_backward(ViewParams v,
                                                                   const float4* __restrict__ rgba, const float* __restrict__ dist,
                                                                   const float4* __restrict__ rgba_grad,
                                                                   const float* __restrict__ dist_grad, float* __restrict__ grad16,
-                                                                  int reference_undo) {
+                                                                  int reference_undo, int kernel_degree) {
     __shared__ FwdEntry stage[kBlock];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x;
     const int px = (int)(tile % (uint32_t)v.grid_x) * kTile + (int)(tid & 15);
@@ -376,11 +376,11 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted_backward(ViewParams v,
                 break;
             }
             float a = 0.f, t = 0.f;
-            if (alive && eval_entry(c, ray, centred, e, a, t)) {
+            if (alive && eval_entry(c, kernel_degree, ray, centred, e, a, t)) {
                 if (kb.num == K) {
                     float ft, fa; uint32_t fi;
                     kb_front(kb, first, ft, fa, fi);
-                    backward_hit(v, c, ray, density12, feat, grad16, fi, fa, ft, pg);
+                    backward_hit(v, c, kernel_degree, ray, density12, feat, grad16, fi, fa, ft, pg);
                     if (pg.T < c.min_transmittance) alive = false;
                     kb_invalidate(kb, first);
                 } else {
@@ -393,31 +393,31 @@ __global__ __launch_bounds__(kBlock) void k_render_sorted_backward(ViewParams v,
 #pragma unroll
     for (int s = 0; s < kKMax; ++s)
         if (alive && s >= kKMax - kb.num) {
-            backward_hit(v, c, ray, density12, feat, grad16, kb.id[s], kb.a[s], kb.t[s], pg);
+            backward_hit(v, c, kernel_degree, ray, density12, feat, grad16, kb.id[s], kb.a[s], kb.t[s], pg);
             if (pg.T < c.min_transmittance) alive = false;
         }
 }
 
 void launch_render_sorted(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12, const float* feat,
                           const float* ray_ori, const float* ray_dir, const uint32_t* ranges, const uint32_t* sorted_ids,
-                          const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits) {
+                          const uint32_t* d_num_intersections, float* rgba, float* dist, float* hits, int kernel_degree) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     hipLaunchKernelGGL(k_render_sorted, dim3(tiles), dim3(kBlock), 0, s, v, c, K, reinterpret_cast<const float4*>(density12), feat,
                        ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids, d_num_intersections,
-                       reinterpret_cast<float4*>(rgba), dist, hits);
+                       reinterpret_cast<float4*>(rgba), dist, hits, kernel_degree);
 }
 
 void launch_render_sorted_bwd(hipStream_t s, const ViewParams& v, const RenderConsts& c, int K, const float* density12,
                               const float* feat, const float* ray_ori, const float* ray_dir, const uint32_t* ranges,
                               const uint32_t* sorted_ids, const float* rgba, const float* dist, const float* rgba_grad,
-                              const float* dist_grad, float* grad16, bool reference_undo) {
+                              const float* dist_grad, float* grad16, bool reference_undo, int kernel_degree) {
     const uint32_t tiles = (uint32_t)(v.grid_x * v.grid_y);
     if (tiles == 0) return;
     hipLaunchKernelGGL(k_render_sorted_backward, dim3(tiles), dim3(kBlock), 0, s, v, c, K, reinterpret_cast<const float4*>(density12),
                        feat, ray_ori, ray_dir, reinterpret_cast<const uint2*>(ranges), sorted_ids,
                        reinterpret_cast<const float4*>(rgba), dist, reinterpret_cast<const float4*>(rgba_grad), dist_grad, grad16,
-                       reference_undo ? 1 : 0);
+                       reference_undo ? 1 : 0, kernel_degree);
 }
 
 }  // namespace gut

@@ -70,13 +70,13 @@ typedef struct GutConfig {
     int32_t abi_version;                  /* GUT_ABI_VERSION */
     int32_t enable_kernel_timings;        /* render.enable_kernel_timings */
     int32_t particle_radiance_sph_degree; /* 3  -> 16 coefficients */
-    int32_t particle_kernel_degree;       /* 2 (quadratic) */
+    int32_t particle_kernel_degree;       /* 2 (quadratic, default); 0, 1, 3, 4, 5, 8: the reference's other generalised Gaussians */
     int32_t k_buffer_size;                /* 0 (unsorted) */
     int32_t global_z_order;               /* 1 */
-    int32_t n_rolling_shutter_iterations; /* 5 (the only value built) */
+    int32_t n_rolling_shutter_iterations; /* 5 by default; 0..64 */
     int32_t ut_require_all_sigma_points;  /* 0 */
     int32_t rect_bounding, tight_opacity_bounding, tile_based_culling; /* 1,1,1 */
-    int32_t enable_hitcounts;             /* 1 */
+    int32_t enable_hitcounts;             /* 1; 0: the hit-count output is all zeros, as in the reference */
     float particle_kernel_min_response;   /* 0.0113 */
     float particle_kernel_min_alpha;      /* 1/255 */
     float particle_kernel_max_alpha;      /* 0.99 */

@@ -50,6 +50,10 @@ typedef struct {
     float ut_alpha, ut_beta, ut_kappa; /* 1, 2, 0                               (3dgut.yaml:19-21) */
     float ut_margin;              /* in_image_margin_factor = 0.1               (3dgut.yaml:22) */
     int32_t rect_bounding, tight_opacity_bounding, tile_culling, global_z_order; /* all 1 */
+    /* kernel variants the reference compiles from its render config (setup_3dgut.py:47-56) */
+    int32_t kernel_degree;              /* particle_kernel_degree = 2: GAUSSIAN_PARTICLE_KERNEL_DEGREE (threedgut.cuh:35); 0,1,3,4,5,8 */
+    int32_t rolling_shutter_iterations; /* splat.n_rolling_shutter_iterations = 5 (threedgut.cuh:63) */
+    int32_t enable_hitcounts;           /* enable_hitcounts = true: GAUSSIAN_ENABLE_HIT_COUNT (rayPayload.cuh:44-46,69-73,126-128) */
 } OracleParams;
 
 typedef struct {
@@ -75,6 +79,7 @@ void oracle_default_params(OracleParams* p) {
     p->ut_alpha = 1.0f; p->ut_beta = 2.0f; p->ut_kappa = 0.0f;
     p->ut_margin = 0.1f;
     p->rect_bounding = 1; p->tight_opacity_bounding = 1; p->tile_culling = 1; p->global_z_order = 1;
+    p->kernel_degree = 2; p->rolling_shutter_iterations = 5; p->enable_hitcounts = 1;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -354,8 +359,9 @@ static void shutter_pose_transform(const float* ps, const float* pe, float a, co
     }
 }
 
-/* projectPointWithShutter<5>, cameraProjections.cuh:146-185 */
-static int project_world_point(const OracleCamera* c, const PoseSet* ps, int W, int H, const float w[3], float tol, float out[2]) {
+/* projectPointWithShutter<N>, cameraProjections.cuh:146-185 (N = GAUSSIAN_N_ROLLING_SHUTTER_ITERATIONS, 5 in render/3dgut.yaml) */
+static int project_world_point(const OracleCamera* c, const PoseSet* ps, int W, int H, const float w[3], float tol, int iterations,
+                               float out[2]) {
     float p[3];
     for (int r = 0; r < 3; ++r)
         p[r] = ps->Rs.c[0][r] * w[0] + ps->Rs.c[1][r] * w[1] + ps->Rs.c[2][r] * w[2] + ps->ts[r];
@@ -367,7 +373,7 @@ static int project_world_point(const OracleCamera* c, const PoseSet* ps, int W, 
         valid = project_camera_point(c, W, H, p, tol, out);
         if (!valid) return 0;
     }
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < iterations; ++it) {
         const float a = relative_shutter_time(c->shutter, W, H, out);
         shutter_pose_transform(c->pose_start, c->pose_end, a, w, p);
         valid = project_camera_point(c, W, H, p, tol, out);
@@ -503,16 +509,16 @@ void oracle_project(const OracleParams* prm, const OracleCamera* cam, int W, int
         quat_to_rows(quat, rows);
         float sig[7][2];
         int nvalid = 0;
-        nvalid += project_world_point(cam, &ps, W, H, pos, prm->ut_margin, sig[0]);
+        nvalid += project_world_point(cam, &ps, W, H, pos, prm->ut_margin, prm->rolling_shutter_iterations, sig[0]);
         float cx = sig[0][0] * w0_mean, cy = sig[0][1] * w0_mean;
         for (int a = 0; a < 3; ++a) {
             const float k = delta_f * scl[a];
             const float d[3] = {k * rows[a][0], k * rows[a][1], k * rows[a][2]};
             const float pp[3] = {pos[0] + d[0], pos[1] + d[1], pos[2] + d[2]};
             const float pm[3] = {pos[0] - d[0], pos[1] - d[1], pos[2] - d[2]};
-            nvalid += project_world_point(cam, &ps, W, H, pp, prm->ut_margin, sig[a + 1]);
+            nvalid += project_world_point(cam, &ps, W, H, pp, prm->ut_margin, prm->rolling_shutter_iterations, sig[a + 1]);
             cx += wi * sig[a + 1][0]; cy += wi * sig[a + 1][1];
-            nvalid += project_world_point(cam, &ps, W, H, pm, prm->ut_margin, sig[a + 4]);
+            nvalid += project_world_point(cam, &ps, W, H, pm, prm->ut_margin, prm->rolling_shutter_iterations, sig[a + 4]);
             cx += wi * sig[a + 4][0]; cy += wi * sig[a + 4][1];
         }
         if (nvalid == 0) continue;
@@ -765,6 +771,46 @@ static float ulp_jitter(float x) {
     return x;
 }
 
+/* particleResponse<n> — kernels/cuda/models/gaussianParticles.cuh:256-306 (generalised Gaussian of degree n, s_n = -4.5 / 3^n;
+ * n = 0 the linear hat; anything else the quadratic default), constants as written there */
+static float kernel_response(int degree, float d2) {
+    switch (degree) {
+    case 8: { const float q = d2 * d2; return expf(-0.000685871056241f * q * q); }
+    case 5: return expf(-0.0185185185185f * d2 * d2 * sqrtf(d2));
+    case 4: return expf(-0.0555555555556f * d2 * d2);
+    case 3: return expf(-0.166666666667f * d2 * sqrtf(d2));
+    case 1: return expf(-1.5f * sqrtf(d2));
+    case 0: return fmaxf(1.0f + -0.329630334487f * sqrtf(d2), 0.0f);
+    default: return expf(-0.5f * d2);
+    }
+}
+/* particleResponseGrd<n> — gaussianParticles.cuh:211-254: dL/d(d2) from dL/d(resp).  The `constexpr float s = <double literal> *
+ * (0.5f * n)` of the reference is a double product rounded once.  Degree 1 is restated AS WRITTEN there: it multiplies by sqrt(d2)
+ * where the derivative of exp(s sqrt(d2)) divides by it (:248-252) — the reference's behaviour, not a correct derivative. */
+static float kernel_response_grad(int degree, float d2, float resp, float g_resp) {
+    switch (degree) {
+    case 8: return (float)(-0.000685871056241 * 4.0) * (d2 * d2) * d2 * resp * g_resp;
+    case 5: return (float)(-0.0185185185185 * 2.5) * d2 * sqrtf(d2) * resp * g_resp;
+    case 4: return (float)(-0.0555555555556 * 2.0) * d2 * resp * g_resp;
+    case 3: return (float)(-0.166666666667 * 1.5) * sqrtf(d2) * resp * g_resp;
+    case 1: return (-1.5f * 0.5f) * sqrtf(d2) * resp * g_resp;
+    case 0: return resp > 0.0f ? (0.5f * -0.329630334487f * (1.0f / sqrtf(d2))) * g_resp : 0.0f;
+    default: return -0.5f * resp * g_resp;
+    }
+}
+/* second fp32 form of the response (variants 1, 2): exp2 of the pre-scaled argument, 1-ulp square roots */
+static float kernel_response_fused(int degree, float d2) {
+    switch (degree) {
+    case 8: { const float q = d2 * d2; return ulp_jitter(exp2f(1.4426950408889634f * (-0.000685871056241f * (q * q)))); }
+    case 5: return ulp_jitter(exp2f(1.4426950408889634f * (-0.0185185185185f * (d2 * d2 * ulp_jitter(sqrtf(d2))))));
+    case 4: return ulp_jitter(exp2f(1.4426950408889634f * (-0.0555555555556f * (d2 * d2))));
+    case 3: return ulp_jitter(exp2f(1.4426950408889634f * (-0.166666666667f * (d2 * ulp_jitter(sqrtf(d2))))));
+    case 1: return ulp_jitter(exp2f(1.4426950408889634f * (-1.5f * ulp_jitter(sqrtf(d2)))));
+    case 0: return fmaxf(fmaf(-0.329630334487f, ulp_jitter(sqrtf(d2)), 1.0f), 0.0f);
+    default: return ulp_jitter(exp2f(-0.72134752f * d2));
+    }
+}
+
 static void eval_hit_fused(const OracleParams* prm, const float* g, const float rows[3][3], const Ray* ray, Hit* h) {
     const float* mu = g; const float* s = g + 8; const float sigma = g[3];
     float is[3], m[3][3];
@@ -788,7 +834,7 @@ static void eval_hit_fused(const OracleParams* prm, const float* g, const float 
     const float c2 = fmaf(h->grdu[0], h->gro[1], -(h->grdu[1] * h->gro[0]));
     const float n2 = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
     h->d2 = l2 > 0.0f ? n2 * ulp_jitter(1.0f / l2) : 0.0f;   /* zero direction: grd = 0, as in variant 0 */
-    h->resp = ulp_jitter(exp2f(-0.72134752f * h->d2));
+    h->resp = kernel_response_fused(prm->kernel_degree, h->d2);
     const float a = h->resp * sigma;
     h->alpha = a < prm->max_alpha ? a : prm->max_alpha;
 }
@@ -810,7 +856,7 @@ static void eval_hit(const OracleParams* prm, const float* g, const float rows[3
     const float c1 = h->grd[2] * h->gro[0] - h->grd[0] * h->gro[2];
     const float c2 = h->grd[0] * h->gro[1] - h->grd[1] * h->gro[0];
     h->d2 = c0 * c0 + c1 * c1 + c2 * c2;
-    h->resp = expf(-0.5f * h->d2);
+    h->resp = kernel_response(prm->kernel_degree, h->d2);
     const float a = h->resp * sigma;
     h->alpha = a < prm->max_alpha ? a : prm->max_alpha;
 }
@@ -825,7 +871,7 @@ static void eval_hit(const OracleParams* prm, const float* g, const float rows[3
  * The two anisotropy factors were missing until round 4 (found with the surface-like stand-in, whose flat 8 : 1 discs made two CPU
  * evaluations differ by up to 9 x the old estimate, gpurun_out/r4/outliers_surface.json); the factor 1/2 keeps the estimate what it
  * was for isotropic Gaussians (sqrt(d2) |gro|), on which every constant of tests/common.py was measured. */
-static float hit_noise(const Hit* h, const float* s) {
+static float hit_noise_d2(const Hit* h, const float* s) {
     const float gn = sqrtf(h->gro[0] * h->gro[0] + h->gro[1] * h->gro[1] + h->gro[2] * h->gro[2]);
     float is_max = 1.0f / s[0];
     if (1.0f / s[1] > is_max) is_max = 1.0f / s[1];
@@ -834,7 +880,28 @@ static float hit_noise(const Hit* h, const float* s) {
     const float lp = sqrtf(h->gposc[0] * h->gposc[0] + h->gposc[1] * h->gposc[1] + h->gposc[2] * h->gposc[2]);
     float spread = 0.5f * (gn * (lu > 0.0f ? is_max / lu : 1.0f) + lp * is_max);
     if (!(spread >= gn)) spread = gn;
-    return sqrtf(h->d2) * spread + 0.5f * h->d2 + 2.0f;
+    return sqrtf(h->d2) * spread;   /* delta(d2) / (2 eps) */
+}
+/* ... for the generalised kernels resp = exp(s d2^(n/2)): delta(resp) / resp = |s| (n/2) d2^(n/2-1) delta(d2) plus the rounding of the
+ * exponent's argument (a few operations instead of one) and of the result; the linear hat (n = 0) has delta(resp) =
+ * |s| delta(d2) / (2 sqrt(d2)), taken relative to the response like the rest (the margins compare against the thresholds). */
+static float hit_noise(const OracleParams* prm, const Hit* h, const float* s) {
+    const float base = hit_noise_d2(h, s);
+    const float d2 = h->d2, r = sqrtf(d2);
+    float slope, arg;   /* |d ln(resp) / d(d2)| and |ln(resp)| */
+    switch (prm->kernel_degree) {
+    case 8: arg = 0.000685871056241f * d2 * d2 * d2 * d2; slope = 4.0f * 0.000685871056241f * d2 * d2 * d2; break;
+    case 5: arg = 0.0185185185185f * d2 * d2 * r; slope = 2.5f * 0.0185185185185f * d2 * r; break;
+    case 4: arg = 0.0555555555556f * d2 * d2; slope = 2.0f * 0.0555555555556f * d2; break;
+    case 3: arg = 0.166666666667f * d2 * r; slope = 1.5f * 0.166666666667f * r; break;
+    case 1: arg = 1.5f * r; slope = r > 0.0f ? 0.75f / r : 0.0f; break;
+    case 0: {
+        const float resp = h->resp > 1e-3f ? h->resp : 1e-3f;
+        return (r > 0.0f ? 0.329630334487f * base / r : 0.0f) / resp + 3.0f;
+    }
+    default: return base + 0.5f * d2 + 2.0f;   /* the quadratic kernel: exactly the estimate every constant of tests/common.py was measured on */
+    }
+    return 2.0f * slope * base + 4.0f * arg + 4.0f;
 }
 
 /* K6: render — gutRenderer.cuh:83-115, gutKBufferRenderer.cuh:108-170,217-292 (K=0),
@@ -889,7 +956,7 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                     float nu = 0.0f;
                     if (margins) {
                         /* fp32 noise of the response in eps units: hit_noise() */
-                        nu = hit_noise(&h, g + 8);
+                        nu = hit_noise(prm, &h, g + 8);
                         const float eps = 5.9604645e-08f;
                         const float mr = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu);
                         if (mr < m_thr) m_thr = mr;
@@ -932,7 +999,7 @@ static void render_impl(const OracleParams* prm, const OracleCamera* cam, int W,
                 rgba[4 * pix] = rgb[0]; rgba[4 * pix + 1] = rgb[1]; rgba[4 * pix + 2] = rgb[2];
                 rgba[4 * pix + 3] = 1.0f - T;
                 dist[pix] = dsum;
-                hits[pix] = (float)nh;
+                hits[pix] = prm->enable_hitcounts ? (float)nh : 0.0f;   /* rayPayload.cuh:126-128: written only when compiled in; the tensor is created zeroed (splatRaster.cpp:198) */
                 if (margins) { margins[2 * pix] = m_thr; margins[2 * pix + 1] = m_trm; }
                 if (margins && g_pixel_budget_out) { g_pixel_budget_out[2 * pix] = pb; g_pixel_budget_out[2 * pix + 1] = pb_hits; }
             }
@@ -964,7 +1031,7 @@ int oracle_debug_ray(const OracleParams* prm, const OracleCamera* cam, int W, in
         Hit h;
         eval_hit(prm, g, rows, &ray, &h);
         const float gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
-        const float nu = hit_noise(&h, g + 8);
+        const float nu = hit_noise(prm, &h, g + 8);
         const int acc = (h.resp > prm->min_kernel_density) && (h.alpha > prm->alpha_threshold);
         if (acc) { T *= (1.0f - h.alpha); if (T < prm->min_transmittance) ray.alive = 0; }
         double* o = out + 8 * (size_t)n++;
@@ -1074,7 +1141,7 @@ void oracle_render_kbuffer(const OracleParams* prm, const OracleCamera* cam, int
                 rgba[4 * pix] = rgb[0]; rgba[4 * pix + 1] = rgb[1]; rgba[4 * pix + 2] = rgb[2];
                 rgba[4 * pix + 3] = 1.0f - T;
                 dist[pix] = dsum;
-                hits[pix] = (float)nh;
+                hits[pix] = prm->enable_hitcounts ? (float)nh : 0.0f;   /* rayPayload.cuh:126-128: written only when compiled in; the tensor is created zeroed (splatRaster.cpp:198) */
             }
     }
 }
@@ -1168,7 +1235,7 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                         quat_to_rows(g + 4, rows);
                         Hit h;
                         eval_hit(prm, g, rows, &ray, &h);
-                        const float nu = hit_noise(&h, g + 8), eps = 5.9604645e-08f;
+                        const float nu = hit_noise(prm, &h, g + 8), eps = 5.9604645e-08f;
                         int prone = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu) < flip_bound;
                         if (h.resp > prm->min_kernel_density)
                             prone |= fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu) < flip_bound;
@@ -1223,7 +1290,7 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                     if (flip_budget) {
                         gn = sqrtf(h.gro[0] * h.gro[0] + h.gro[1] * h.gro[1] + h.gro[2] * h.gro[2]);
                         const float eps = 5.9604645e-08f;
-                        nu = hit_noise(&h, g + 8);
+                        nu = hit_noise(prm, &h, g + 8);
                         prone = fabsf(h.resp - prm->min_kernel_density) / (prm->min_kernel_density * eps * nu) < flip_bound;
                         if (h.resp > prm->min_kernel_density)
                             prone |= fabsf(h.resp * g[3] - prm->alpha_threshold) / (prm->alpha_threshold * eps * nu) < flip_bound;
@@ -1264,7 +1331,7 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                                     T * (f[2] - res_rad[2]) * rgb_g[2];
                     const float d_sigma = h.resp * G;
                     const float g_resp = sigma * G;
-                    const float g_d2 = -0.5f * h.resp * g_resp;
+                    const float g_d2 = kernel_response_grad(prm->kernel_degree, h.d2, h.resp, g_resp);
                     const float cr[3] = {h.grd[1] * h.gro[2] - h.grd[2] * h.gro[1], h.grd[2] * h.gro[0] - h.grd[0] * h.gro[2],
                                          h.grd[0] * h.gro[1] - h.grd[1] * h.gro[0]};
                     const float gc[3] = {2 * cr[0] * g_d2, 2 * cr[1] * g_d2, 2 * cr[2] * g_d2};

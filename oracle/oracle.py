@@ -21,6 +21,7 @@ class OracleParams(C.Structure):
         ("ut_alpha", C.c_float), ("ut_beta", C.c_float), ("ut_kappa", C.c_float), ("ut_margin", C.c_float),
         ("rect_bounding", C.c_int32), ("tight_opacity_bounding", C.c_int32), ("tile_culling", C.c_int32),
         ("global_z_order", C.c_int32),
+        ("kernel_degree", C.c_int32), ("rolling_shutter_iterations", C.c_int32), ("enable_hitcounts", C.c_int32),
     ]
 
 

@@ -84,7 +84,59 @@ def world_rays(ray_ori, ray_dir, Rinv, cam_pos):
     return o, d
 
 
-def _composite_block(o, d, tmin, tmax, mu, rows, s, sigma, feat, state):
+# generalised Gaussian kernels (render.particle_kernel_degree): resp = exp(-S_n d2^(n/2)), S_n = 4.5 / 3^n as the reference writes
+# them (kernels/cuda/models/gaussianParticles.cuh:256-306, slang/models/gaussianParticles.slang:119-164); n = 0 is the linear hat
+_KERNEL_S = {8: 0.000685871056241, 5: 0.0185185185185, 4: 0.0555555555556, 3: 0.166666666667, 2: 0.5, 1: 1.5, 0: 0.329630334487}
+
+
+def kernel_response(d2, degree=2):
+    """The kernel's response as a plain differentiable expression (true derivative under autograd: what the reference's slang
+    autodiff gives the sorted variant)."""
+    if degree not in _KERNEL_S:
+        degree = 2   # particleResponse<>'s default case
+    sn = _KERNEL_S[degree]
+    if degree == 0:
+        return (1.0 - sn * torch.sqrt(d2)).clamp(min=0.0)
+    if degree == 2:
+        return torch.exp(-0.5 * d2)
+    return torch.exp(-sn * d2 ** (0.5 * degree))
+
+
+class _ReferenceResponse(torch.autograd.Function):
+    """Same forward; the backward is particleResponseGrd<n> AS THE REFERENCE WRITES IT for its unsorted backward
+    (gaussianParticles.cuh:211-254).  For every degree but 1 that is the true derivative; for degree 1 it multiplies by sqrt(d2)
+    where the derivative of exp(s sqrt(d2)) divides by it (:248-252)."""
+
+    @staticmethod
+    def forward(ctx, d2, degree):
+        resp = kernel_response(d2, degree)
+        ctx.save_for_backward(d2, resp)
+        ctx.degree = degree if degree in _KERNEL_S else 2
+        return resp
+
+    @staticmethod
+    def backward(ctx, g):
+        d2, resp = ctx.saved_tensors
+        n = ctx.degree
+        sn = _KERNEL_S[n]
+        if n == 8:
+            out = -sn * 4.0 * d2 * d2 * d2 * resp * g
+        elif n == 5:
+            out = -sn * 2.5 * d2 * torch.sqrt(d2) * resp * g
+        elif n == 4:
+            out = -sn * 2.0 * d2 * resp * g
+        elif n == 3:
+            out = -sn * 1.5 * torch.sqrt(d2) * resp * g
+        elif n == 1:
+            out = -sn * 0.5 * torch.sqrt(d2) * resp * g
+        elif n == 0:
+            out = torch.where(resp > 0, 0.5 * -sn / torch.sqrt(d2) * g, torch.zeros_like(g))
+        else:
+            out = -0.5 * resp * g
+        return out, None
+
+
+def _composite_block(o, d, tmin, tmax, mu, rows, s, sigma, feat, state, kernel_degree=2, reference_response_grad=False):
     """One block of P rays against L depth-ordered Gaussians; state = (T, alive, rgb, dist, hits)."""
     T_c, alive_c, rgb, dist, hits = state
     gposc = o[:, None, :] - mu[None]
@@ -93,7 +145,8 @@ def _composite_block(o, d, tmin, tmax, mu, rows, s, sigma, feat, state):
     grdu = torch.einsum("lij,pj->pli", rows, d) / s
     grd = grdu / grdu.norm(dim=-1, keepdim=True)
     c = torch.cross(grd, gro, dim=-1)
-    resp = torch.exp(-0.5 * (c * c).sum(-1))
+    d2 = (c * c).sum(-1)
+    resp = _ReferenceResponse.apply(d2, kernel_degree) if reference_response_grad else kernel_response(d2, kernel_degree)
     a = resp * sigma[None, :]
     alpha = a + (a.clamp(max=ALPHA_MAX) - a).detach()
     p = -(grd * gro).sum(-1)
@@ -126,7 +179,7 @@ def _ray_limits(o, d):
 
 
 def render_tiled(params, tq, W, H, ray_ori, ray_dir, tile_ranges, sorted_ids, sh_degree=3, dtype=torch.float64,
-                 chunk=128):
+                 chunk=128, kernel_degree=2, reference_response_grad=False):
     """params: dict of tensors positions[N,3], rotation[N,4], scale[N,3], density[N,1], features[N,48].
     Returns rgba [H,W,4], dist [H,W], hits [H,W] (torch, differentiable)."""
     R, t, Rinv, cam_pos = pose_matrices(tq, dtype)
@@ -156,7 +209,8 @@ def render_tiled(params, tq, W, H, ray_ori, ray_dir, tile_ranges, sorted_ids, sh
             ids = ids[ids != 0xFFFFFFFF]
             if ids.numel() == 0 or not bool(state[1].any()):
                 break
-            state = _composite_block(o, d, tmin, tmax, pos[ids], rows_all[ids], scl[ids], dns[ids, 0], feat_all[ids], state)
+            state = _composite_block(o, d, tmin, tmax, pos[ids], rows_all[ids], scl[ids], dns[ids, 0], feat_all[ids], state,
+                                     kernel_degree, reference_response_grad)
         T, _, rgb, dist, hits = state
         out = torch.cat([rgb, (1 - T)[:, None]], dim=1)
         rgba = rgba.index_put((pix[valid],), out[valid])
@@ -366,7 +420,7 @@ class _ReferenceUndoColour(torch.autograd.Function):
 
 
 def composite_ordered(params, tq, W, H, ray_ori, ray_dir, order_ids, order_count, sh_degree=3, dtype=torch.float64,
-                      reference_undo_colour=False):
+                      reference_undo_colour=False, kernel_degree=2):
     """Exact (autograd) compositing of each pixel's particles in a GIVEN order — the sorted variant's semantics
     (k_buffer_size > 0): the reference differentiates it with slang autodiff (gaussianParticles.slang:394-451,
     shRadiativeParticles.slang:179-207), i.e. true derivatives incl. min(0.99, .) and the hit distance.
@@ -389,7 +443,7 @@ def composite_ordered(params, tq, W, H, ray_ori, ray_dir, order_ids, order_count
     grdu = torch.einsum("plij,pj->pli", rws, d) / s
     grd = grdu / grdu.norm(dim=-1, keepdim=True)
     c = torch.cross(grd, gro, dim=-1)
-    resp = torch.exp(-0.5 * (c * c).sum(-1))
+    resp = kernel_response((c * c).sum(-1), kernel_degree)
     alpha = (resp * sg).clamp(max=ALPHA_MAX)
     alpha = torch.where(valid, alpha, torch.zeros_like(alpha))
     hit_t = (s * grd * (-(grd * gro).sum(-1))[..., None]).norm(dim=-1)

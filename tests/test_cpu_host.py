@@ -76,7 +76,7 @@ def test_default_config_and_conf_mapping():
 
 def test_unsupported_variant_is_rejected_without_gpu_work():
     lib = capi.load()
-    cfg = tracer_mod.config_from_conf({"render": {"particle_kernel_degree": 4}})
+    cfg = tracer_mod.config_from_conf({"render": {"particle_kernel_degree": 7}})   # not one of the reference's kernels (0,1,2,3,4,5,8)
     h = C.c_void_p()
     rc = lib.gut_create(C.byref(cfg), 0, C.byref(h))
     assert rc != 0 and b"particle_kernel_degree" in lib.gut_last_error()

@@ -432,3 +432,97 @@ def test_two_fp32_evaluations_measure_the_tolerance_model(name):
         rep["sh"] = round(r_full, 3)
         report[v] = rep
     print(f"[band {name}] {report}")
+
+
+KERNEL_DEGREES = [0, 1, 3, 4, 5, 8]
+
+
+def test_generalised_kernel_known_answers():
+    """render.particle_kernel_degree: the response of every generalised Gaussian the reference compiles (gaussianParticles.cuh:256-306)
+    at known arguments — s_n = -4.5 / 3^n makes every kernel's response exp(-4.5) at d2 = 9 (three "sigma"), the linear hat reaches
+    zero at sqrt(d2) = 1 / 0.3296 — through the oracle's per-ray debug export on a one-Gaussian scene."""
+    for n in KERNEL_DEGREES + [2]:
+        prm = oracle.default_params()
+        prm.kernel_degree = n
+        sc = {"positions": np.zeros((1, 3), np.float32), "rotation": np.array([[1, 0, 0, 0]], np.float32),
+              "scale": np.full((1, 3), 0.5, np.float32), "density": np.array([[0.9]], np.float32), "features": np.zeros((1, 48), np.float32)}
+        W = H = 32
+        view = make_view("pinhole", W, H, cams.look_at_c2w((0, 0, -4.0), (0, 0, 0)), fx=40.0)
+        f = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], params=prm)
+        # the ray through pixel (px, 16) passes the centre at distance r = 4 * |dx| / fx (to first order): d2 = (r / 0.5)^2
+        for px in (16, 18, 21, 25):
+            dbg = oracle.debug_ray(view["oracle_cam"], f, px, 16, params=prm)
+            if not len(dbg):
+                continue
+            d2 = float(dbg[0, 1])
+            sn = prt._KERNEL_S[n]
+            want = max(1.0 - sn * math.sqrt(d2), 0.0) if n == 0 else math.exp(-sn * d2 ** (0.5 * n))
+            assert abs(float(dbg[0, 2]) - want) <= 2e-6 * max(want, 1e-3), (n, px, d2)
+    for n in (1, 3, 4, 5, 8, 2):
+        assert abs(prt._KERNEL_S[n] * 9.0 ** (0.5 * n) - 4.5) <= 1e-9 * 4.5 * 3 ** n
+
+
+@pytest.mark.parametrize("degree", KERNEL_DEGREES)
+def test_generalised_kernels_match_float64_autograd(degree):
+    """The oracle's forward and backward for render.particle_kernel_degree != 2 against the float64 restatement: colours, hit counts,
+    and every parameter gradient with the response's backward taken AS THE REFERENCE WRITES IT (particleResponseGrd<n>,
+    gaussianParticles.cuh:211-254).  For every degree but 1 that is also the true derivative (plain autograd agrees); for degree 1 the
+    reference multiplies by sqrt(d2) where the derivative divides by it — restated, and this test shows the two differ."""
+    sc = scenes.scene_c1(250, seed=5)
+    W, H = 48, 40
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.3, 0.2, -3.5), (0, 0, 0)), fx=50)
+    prm = oracle.default_params()
+    prm.kernel_degree = degree
+    f = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], params=prm)
+    f2 = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"])
+    assert np.array_equal(f["sorted_keys"], f2["sorted_keys"])   # projection and binning do not know the kernel (gutProjector.cuh)
+    assert np.abs(f["rgba"] - f2["rgba"]).max() > 1e-2           # ... the compositor does
+    rg = np.random.default_rng(0).normal(size=(H, W, 4)).astype(np.float32)
+    dg, sg, _ = oracle.backward(view["oracle_cam"], f, rg, np.zeros((H, W, 1), np.float32), params=prm)
+    rel = lambda a, b: np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
+    grads = {}
+    for as_written in (True, False):
+        params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sc.items()}
+        rgba, dist, hits = prt.render_tiled(params, view["tq"], W, H, view["ro"], view["rd"], f["tile_ranges"], f["sorted_ids"],
+                                            kernel_degree=degree, reference_response_grad=as_written)
+        assert np.abs(rgba.detach().numpy() - f["rgba"]).max() <= 2e-5
+        assert np.abs(hits.numpy() - f["hits"][..., 0]).max() == 0
+        (rgba * torch.tensor(rg, dtype=torch.float64)).sum().backward()
+        grads[as_written] = params
+    p = grads[True]
+    tol = 5e-5 if degree != 0 else 5e-4   # the hat's 1 / sqrt(d2) amplifies fp32 rounding near the centre
+    assert rel(p["positions"].grad.numpy(), dg[:, 0:3]) <= tol
+    assert rel(p["density"].grad.numpy()[:, 0], dg[:, 3]) <= tol
+    assert rel(p["rotation"].grad.numpy(), dg[:, 4:8]) <= tol
+    assert rel(p["scale"].grad.numpy(), dg[:, 8:11]) <= tol
+    assert rel(p["features"].grad.numpy(), sg) <= tol
+    true_vs_written = rel(grads[False]["positions"].grad.numpy(), p["positions"].grad.numpy())
+    if degree == 1:
+        assert true_vs_written > 0.05, "degree 1: the reference's response gradient is NOT the derivative"
+    else:
+        assert true_vs_written <= 1e-9
+
+
+def test_rolling_shutter_iterations_and_hit_count_options():
+    """splat.n_rolling_shutter_iterations (cameraProjections.cuh:174: the loop count of projectPointWithShutter) and enable_hitcounts
+    (rayPayload.cuh:126-128) in the oracle: fewer iterations move the projection of a moving camera, more than enough change nothing;
+    without hit counts that output stays zero and nothing else changes."""
+    sc = scenes.scene_c1(400, seed=3)
+    W, H = 64, 48
+    view = make_view("pinhole", W, H, cams.look_at_c2w((0.2, 0.1, -3.5), (0, 0, 0)), fx=60)
+    pose_mod = importlib.import_module("3dgrut_amd.pose")
+    tq_end = pose_mod.sensor_pose_from_c2w(cams.look_at_c2w((0.5, 0.0, -3.3), (0.1, 0, 0))).T_world_sensors[0]
+    view["oracle_cam"] = dict(view["oracle_cam"], shutter=0, pose_end=tq_end)
+    out = {}
+    for it in (0, 1, 5, 9):
+        prm = oracle.default_params()
+        prm.rolling_shutter_iterations = it
+        out[it] = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], params=prm)
+    assert not np.array_equal(out[0]["proj_pos"], out[5]["proj_pos"]) and not np.array_equal(out[1]["proj_pos"], out[5]["proj_pos"])
+    cnt = (out[5]["tiles_count"] > 0) & (out[9]["tiles_count"] > 0)
+    assert np.abs(out[9]["proj_pos"][cnt] - out[5]["proj_pos"][cnt]).max() <= 1e-3   # converged
+    prm = oracle.default_params()
+    prm.enable_hitcounts = 0
+    off = oracle.forward(view["oracle_cam"], W, H, scenes.pack_density(sc), sc["features"], view["ro"], view["rd"], params=prm)
+    assert out[5]["hits"].max() > 0 and off["hits"].max() == 0
+    assert np.array_equal(off["rgba"], out[5]["rgba"]) and np.array_equal(off["dist"], out[5]["dist"])

@@ -282,6 +282,17 @@ TOGGLES = {
     "thresholds_loose": ({"particle_kernel_min_response": 0.002, "particle_kernel_min_alpha": 0.001, "particle_kernel_max_alpha": 0.999,
                           "min_transmittance": 1e-6},
                          dict(min_kernel_density=0.002, alpha_threshold=0.001, max_alpha=0.999, min_transmittance=1e-6)),
+    # the reference's generalised Gaussian kernels (GAUSSIAN_PARTICLE_KERNEL_DEGREE, threedgut.cuh:35; particleResponse<> /
+    # particleResponseGrd<>, gaussianParticles.cuh:211-306): the `kGeneral` instantiations of the compositors (gut_render_general.hip)
+    "kernel_degree_0_linear": ({"particle_kernel_degree": 0}, dict(kernel_degree=0)),
+    "kernel_degree_1_laplacian": ({"particle_kernel_degree": 1}, dict(kernel_degree=1)),
+    "kernel_degree_3": ({"particle_kernel_degree": 3}, dict(kernel_degree=3)),
+    "kernel_degree_4": ({"particle_kernel_degree": 4}, dict(kernel_degree=4)),
+    "kernel_degree_5": ({"particle_kernel_degree": 5}, dict(kernel_degree=5)),
+    "kernel_degree_8": ({"particle_kernel_degree": 8}, dict(kernel_degree=8)),
+    "kernel_degree_4_thresholds": ({"particle_kernel_degree": 4, "particle_kernel_min_response": 0.05, "particle_kernel_min_alpha": 0.01},
+                                   dict(kernel_degree=4, min_kernel_density=0.05, alpha_threshold=0.01)),
+    "hitcounts_off": ({"enable_hitcounts": False}, dict(enable_hitcounts=0)),                              # rayPayload.cuh:44-46,126-128
 }
 
 
@@ -305,7 +316,8 @@ def test_config_toggles_against_the_oracle(name, toggle):
     ref0 = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
     assert ref["M"] > 0
     changed = (ref["M"] != ref0["M"] or not np.array_equal(ref["sorted_keys"], ref0["sorted_keys"]) or not np.array_equal(ref["rgba"], ref0["rgba"])
-               or not np.array_equal(ref["proj_pos"], ref0["proj_pos"]) or not np.array_equal(ref["extent"], ref0["extent"]))
+               or not np.array_equal(ref["proj_pos"], ref0["proj_pos"]) or not np.array_equal(ref["extent"], ref0["extent"])
+               or not np.array_equal(ref["hits"], ref0["hits"]))
     assert changed, f"{toggle} changes nothing on {name}: the case does not test it"
     rng = np.random.default_rng(17)
     rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
@@ -402,6 +414,45 @@ def test_rolling_shutter_projection(shutter, kind):
     assert not np.array_equal(glob["proj_pos"], ref["proj_pos"])
 
 
+@pytest.mark.parametrize("iterations", [0, 2, 9])
+@pytest.mark.parametrize("kind", ["pinhole", "fisheye_distorted"])
+def test_rolling_shutter_iteration_count(iterations, kind):
+    """render.splat.n_rolling_shutter_iterations away from 5 (GAUSSIAN_N_ROLLING_SHUTTER_ITERATIONS, the trip count of
+    projectPointWithShutter's refinement loop, cameraProjections.cuh:174): a run-time value here.  Same checks as the default count,
+    and a low count must really move the projection."""
+    pose_mod = importlib.import_module("3dgrut_amd.pose")
+    sc = scenes.scene_c1(700, 47)
+    W, H = 96, 80
+    distortion = FISHEYE_DIST if kind == "fisheye_distorted" else None
+    kind = "fisheye" if distortion else kind
+    view = make_view(kind, W, H, cams.look_at_c2w((0.1, 0.0, -3.0 if kind == "pinhole" else -1.6), (0, 0, 0)), fx=90 if kind == "pinhole" else None,
+                     distortion=distortion)
+    end_c2w = cams.look_at_c2w((0.25, -0.1, -2.9 if kind == "pinhole" else -1.55), (0.05, 0.0, 0.0))
+    tq_end = pose_mod.sensor_pose_from_c2w(end_c2w).T_world_sensors[0]
+    ocam = dict(view["oracle_cam"], shutter=0, pose_end=tq_end)
+    model, d12, sph = _oracle_inputs(sc, 3)
+    prm = oracle.default_params()
+    prm.rolling_shutter_iterations = iterations
+    ref = oracle.forward(ocam, W, H, d12, sph, view["ro"], view["rd"], sh_degree=3, params=prm)
+    ref5 = oracle.forward(ocam, W, H, d12, sph, view["ro"], view["rd"], sh_degree=3)
+    if iterations < 5:
+        assert not np.array_equal(ref["proj_pos"], ref5["proj_pos"])
+    raster = gut.SplatRaster({"render": {"splat": {"n_rolling_shutter_iterations": iterations}}})
+    sensor, poses = gut.Tracer.create_camera_parameters(to_batch(view, DEV))
+    sensor.cam.shutter = 0
+    ro = torch.as_tensor(view["ro"], device=DEV); rd = torch.as_tensor(view["rd"], device=DEV)
+    rgba, dist, hits, vis = raster.trace(0, 3, torch.as_tensor(d12, device=DEV), torch.as_tensor(sph, device=DEV), ro, rd, None, sensor,
+                                         0, 1, poses.T_world_sensors[0], tq_end)
+    assert raster.stats()["num_intersections"] == ref["M"] and ref["M"] > 0
+    for key in ("tiles_count", "sorted_ids"):
+        assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
+    assert np.array_equal(raster.debug_buffer("sorted_keys").cpu().numpy().view(np.uint64), ref["sorted_keys"])
+    for key in ("proj_pos", "conic_opacity", "extent", "depth"):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)), key
+    assert np.abs(rgba.cpu().numpy() - ref["rgba"]).max() <= 2e-4
+
+
 def test_timings_surface():
     sc = scenes.scene_c1(500, 2)
     view = make_view("pinhole", 64, 64, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64)
@@ -416,11 +467,11 @@ def test_timings_surface():
 # ---------------------------------------------------------------------------------------------------
 # sorted variant (render.splat.k_buffer_size > 0), SURVEY §8a row a14
 # ---------------------------------------------------------------------------------------------------
-def _run_sorted(view, model, K, rgba_grad=None, dist_grad=None, reference_backward=None):
+def _run_sorted(view, model, K, rgba_grad=None, dist_grad=None, reference_backward=None, kernel_degree=2):
     splat = {"k_buffer_size": K}
     if reference_backward is not None:          # None: the library's default (the reference's form since ABI 5)
         splat["sorted_reference_backward"] = reference_backward
-    tr = gut.Tracer({"render": {"splat": splat}})
+    tr = gut.Tracer({"render": {"splat": splat, "particle_kernel_degree": kernel_degree}})
     out = tr.render(model, to_batch(view, DEV), train=True, frame_id=0)
     if rgba_grad is not None:
         rg = torch.as_tensor(rgba_grad, device=DEV)
@@ -456,6 +507,45 @@ def test_sorted_variant_forward(name, K):
         # K=1 composites in list order: must agree with the unsorted compositor
         ref0 = _run_gpu(sc, view, 3, model=model)["out"]
         assert (out["pred_rgb"] - ref0["pred_rgb"]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("degree", [0, 1, 4])
+def test_sorted_variant_with_generalised_kernels(degree):
+    """k_buffer_size > 0 together with particle_kernel_degree != 2: forward against oracle_render_kbuffer, backward against float64
+    autograd of the ordered composite — the TRUE derivative of the response, which is what slang autodiff gives the reference's sorted
+    variant (gaussianParticles.slang:119-164), also for degree 1 where the unsorted CUDA backward has its own form."""
+    prt = importlib.import_module("oracle.per_ray_torch")
+    K = 8
+    mk, kind, W, H, (eye, tgt), kw = CASES["c1_pinhole_128"]
+    sc = mk()
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    rng = np.random.default_rng(15)
+    rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
+    model, d12, sph = _oracle_inputs(sc, 3)
+    prm = oracle.default_params()
+    prm.kernel_degree = degree
+    fwd = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=3, params=prm)
+    max_order = int(fwd["hits"].max()) + 64
+    ref = oracle.render_kbuffer(view["oracle_cam"], fwd, K=K, max_order=max_order, params=prm)
+    L = max(int(ref["order_count"].max()), 1)
+    params = dict(positions=d12[:, 0:3], density=d12[:, 3:4], rotation=d12[:, 4:8], scale=d12[:, 8:11], features=sph)
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    rgba, dist = prt.composite_ordered(params, view["tq"], W, H, view["ro"], view["rd"], ref["order_ids"][:, :L], ref["order_count"],
+                                       kernel_degree=degree)
+    assert np.abs(rgba.detach().numpy().reshape(H, W, 4) - ref["rgba"]).max() <= 5e-5
+    (rgba * torch.tensor(rgba_grad.reshape(-1, 4), dtype=torch.float64)).sum().backward()
+    dens_g = np.zeros((d12.shape[0], 12))
+    dens_g[:, 0:3] = params["positions"].grad.numpy(); dens_g[:, 3:4] = params["density"].grad.numpy()
+    dens_g[:, 4:8] = params["rotation"].grad.numpy(); dens_g[:, 8:11] = params["scale"].grad.numpy()
+    exp = _activated_grads(model, dens_g, params["features"].grad.numpy())
+    out = _run_sorted(view, model, K, rgba_grad=rgba_grad, reference_backward=False, kernel_degree=degree)
+    rgb = out["pred_rgb"][0].detach().cpu().numpy()
+    bad = np.abs(rgb - ref["rgba"][..., :3]).max(-1) > 2e-4
+    assert bad.mean() <= 1e-3, f"{bad.sum()} of {bad.size} pixels differ"
+    assert (out["hits_count"][0].detach().cpu().numpy() != ref["hits"]).mean() <= 2e-3
+    for k, e in exp.items():
+        err = rel_l2(getattr(model, k).grad.cpu().numpy(), e)
+        assert err <= (2e-3 if degree else 5e-3), f"degree {degree}/{k}: rel L2 {err}"
 
 
 @pytest.mark.parametrize("name", ["c1_pinhole_128", "fisheye_144x96", "dense_big_splats"])
