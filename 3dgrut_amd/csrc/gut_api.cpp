@@ -136,6 +136,7 @@ struct gut_context {
     DevBuf tiles_count, tiles_offset, proj_pos, conic_opacity, extent, depth, feat, grad16, scan_temp;
     float* stat_accum = nullptr;    // gut_set_position_gradient_statistics: consumed by the next gut_optimize_after_bwd
     int32_t* stat_denom = nullptr;
+    DevBuf sph_widened, sph_grad_wide;   // particle_radiance_sph_degree < 3: the [N,48] rows the kernels read / write
     DevBuf packed12;   // gut_trace_fields: the [N,12] rows packed from the caller's four tensors (kept for its backward)
     bool packed_valid = false;
     bool packed_raw = false;   // packed12 holds rows ACTIVATED by the library from the model's raw tensors (gut_trace_raw_model_fields)
@@ -362,7 +363,10 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
     }
     if (cfg->k_buffer_size < 0 || cfg->k_buffer_size > 16)
         return fail("k_buffer_size=%d: supported range is 0 (unsorted) .. 16", cfg->k_buffer_size);
-    if (cfg->particle_radiance_sph_degree != 3) return fail("particle_radiance_sph_degree=%d: only degree 3 (16 coefficients) is built", cfg->particle_radiance_sph_degree);
+    // PARTICLE_RADIANCE_NUM_COEFFS = (degree + 1)^2 (setup_3dgut.py:48): the width of the radiance rows.  The kernels are built for 16
+    // coefficients; narrower rows are widened on the way in and the gradient narrowed on the way out (trace_fwd_impl / trace_bwd_impl)
+    if (cfg->particle_radiance_sph_degree < 0 || cfg->particle_radiance_sph_degree > 3)
+        return fail("particle_radiance_sph_degree=%d outside 0..3", cfg->particle_radiance_sph_degree);
     if (cfg->ut_require_all_sigma_points != 0) return fail("ut_require_all_sigma_points must be false (static_assert in threedgut.cuh:73)");
     if (cfg->n_rolling_shutter_iterations < 0 || cfg->n_rolling_shutter_iterations > 64)
         return fail("n_rolling_shutter_iterations=%d outside 0..64", cfg->n_rolling_shutter_iterations);
@@ -452,6 +456,14 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     if (num_active_features < 0 || num_active_features > 3) return fail("gut_trace: SH degree %d outside 0..3", num_active_features);
     if (num_particles && (!d_particle_density || !d_particle_radiance || !d_particle_visibility))
         return fail("gut_trace: null particle buffers with %u particles", num_particles);
+    if (h->cfg.particle_radiance_sph_degree != 3) {
+        if (num_active_features > h->cfg.particle_radiance_sph_degree)
+            return fail("gut_trace: %d active SH degrees, the handle was created for particle_radiance_sph_degree=%d", num_active_features,
+                        h->cfg.particle_radiance_sph_degree);
+        if (d_features_albedo)
+            return fail("gut_trace_model_fields: features_specular [N,45] belongs to particle_radiance_sph_degree=3; this handle has %d "
+                        "(use gut_trace / gut_trace_fields with the concatenated rows)", h->cfg.particle_radiance_sph_degree);
+    }
     std::lock_guard<std::mutex> lock(h->mu);
     hipStream_t s = static_cast<hipStream_t>(stream_);
     DeviceGuard dev_guard;
@@ -510,6 +522,15 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     HIP_TRY(hipMemsetAsync(h->trav_bwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
     HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
     mark(0);
+    if (h->cfg.particle_radiance_sph_degree != 3 && n) {
+        // rows of 3 (degree + 1)^2 floats (gaussianParticles.cuh:208-216 reads PARTICLE_RADIANCE_NUM_COEFFS coefficients per particle):
+        // zero-extended to the 16 coefficients the projection kernel is laid out for; the coefficients above the active degree are
+        // never evaluated, so the render is that of the narrower variant
+        const uint32_t w = 3u * (uint32_t)((h->cfg.particle_radiance_sph_degree + 1) * (h->cfg.particle_radiance_sph_degree + 1));
+        HIP_TRY(h->sph_widened.ensure(sizeof(float) * 48 * (size_t)n));
+        gut::launch_resize_sph_rows(s, n, w, 48u, d_particle_radiance, h->sph_widened.as<float>());
+        d_particle_radiance = h->sph_widened.as<float>();
+    }
     gut::launch_project(s, v, h->consts, n, num_active_features, d_particle_density, d_particle_radiance,
                         h->tiles_count.as<uint32_t>(), h->proj_pos.as<float>(), h->conic_opacity.as<float>(),
                         h->extent.as<float>(), h->depth.as<float>(), h->feat.as<float>(), d_particle_visibility,
@@ -877,6 +898,12 @@ static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     if (h->early_ran && !(flags & GUT_BWD_SKIP_EPILOGUE))
         return fail("gut_trace_bwd: gut_optimize_rows_without_gradient was called for this forward: the backward must be "
                     "gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) followed by gut_optimize_after_bwd");
+    float* narrow_radiance_grad = nullptr;   // particle_radiance_sph_degree < 3: the caller's [N, 3 (degree + 1)^2] gradient
+    if (h->cfg.particle_radiance_sph_degree != 3 && !(flags & GUT_BWD_SKIP_EPILOGUE)) {
+        if ((flags & GUT_BWD_COMPACT_RADIANCE_GRADS) || fields.alb)
+            return fail("gut_trace_bwd: particle_radiance_sph_degree=%d supports the packed radiance gradient only", h->cfg.particle_radiance_sph_degree);
+        narrow_radiance_grad = d_particle_radiance_grad;
+    }
     DeviceGuard dev_guard;
     HIP_TRY(dev_guard.set(h->device));
     gut::ViewParams v;
@@ -888,6 +915,10 @@ static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
         const void* before = h->grad16.p;
         HIP_TRY(h->grad16.ensure(sizeof(float) * 16 * (size_t)n));
         if (h->grad16.p != before) h->grad16_zero = false;  // fresh allocation
+    }
+    if (narrow_radiance_grad) {
+        HIP_TRY(h->sph_grad_wide.ensure(sizeof(float) * 48 * (size_t)n));
+        d_particle_radiance_grad = h->sph_grad_wide.as<float>();
     }
 
     const bool timing = h->cfg.enable_kernel_timings != 0;
@@ -931,6 +962,10 @@ static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
             gut::launch_project_bwd(s, v, n, h->sh_degree, d_particle_density, h->tiles_count.as<uint32_t>(), h->feat.as<float>(),
                                     h->grad16.as<float>(), d_particle_density_grad, d_particle_radiance_grad,
                                     (flags & GUT_BWD_RAW_PARAMETER_GRADS) != 0, fields);
+        if (narrow_radiance_grad) {
+            const uint32_t w = 3u * (uint32_t)((h->cfg.particle_radiance_sph_degree + 1) * (h->cfg.particle_radiance_sph_degree + 1));
+            gut::launch_resize_sph_rows(s, n, 48u, w, h->sph_grad_wide.as<float>(), narrow_radiance_grad);
+        }
         h->grad16_zero = true;  // the epilogue zeroed every row K7 could have touched (the rows with tiles)
     }
     mark(11);
@@ -950,6 +985,8 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
                            const float* lr12, const float* lr48, float beta1, float beta2, float eps, uint32_t step,
                            const float* d_visibility, float* d_act12_out, const GutLazyMoments* lazy) {
     if (!h) return fail("gut_optimize_after_bwd: null handle");
+    if (h->cfg.particle_radiance_sph_degree != 3)
+        return fail("gut_optimize_after_bwd: the fused optimiser is built for particle_radiance_sph_degree=3 (59 parameters per Gaussian), this handle has %d", h->cfg.particle_radiance_sph_degree);
     std::lock_guard<std::mutex> lock(h->mu);
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (!h->have_backward || h->fwd_stream != s)
@@ -1096,6 +1133,8 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
                                        float* d_sh_m, float* d_sh_v, const float* lr12, const float* lr48, float beta1, float beta2,
                                        float eps, uint32_t step, float* d_act12_out, const GutLazyMoments* lazy) {
     if (!h) return fail("gut_optimize_rows_without_gradient: null handle");
+    if (h->cfg.particle_radiance_sph_degree != 3)
+        return fail("gut_optimize_rows_without_gradient: the fused optimiser is built for particle_radiance_sph_degree=3 (59 parameters per Gaussian), this handle has %d", h->cfg.particle_radiance_sph_degree);
     std::lock_guard<std::mutex> lock(h->mu);
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (!h->have_forward || h->fwd_stream != s)

@@ -112,6 +112,9 @@ void launch_project_bwd(hipStream_t s, const ViewParams& v, uint32_t n, int sh_d
                         float* density_grad12, float* sph_grad48, bool raw_grads, const GradFields& fields = GradFields());
 void launch_pack_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns, const float* rot, const float* scl,
                         float* density12);
+// out[row][c] = c < in_width ? in[row][c] : 0 for c < out_width: widens [N, 3 (d+1)^2] radiance rows to the kernels' 48 columns and
+// narrows the [N,48] gradient back (render.particle_radiance_sph_degree < 3)
+void launch_resize_sph_rows(hipStream_t s, uint32_t n, uint32_t in_width, uint32_t out_width, const float* in, float* out);
 void launch_pack_activate_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns_logit, const float* rot_raw,
                                  const float* log_scl, float* act12);   // gut_train.hip (activate_row)
 

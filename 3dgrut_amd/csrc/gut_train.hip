@@ -918,6 +918,20 @@ __global__ __launch_bounds__(kBlock) void k_sync_moments(uint32_t n, float4* __r
 }  // namespace gut
 
 namespace gut {
+__global__ __launch_bounds__(256) void k_resize_sph_rows(uint32_t n, uint32_t in_width, uint32_t out_width, const float* __restrict__ in,
+                                                         float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (size_t)n * out_width) return;
+    const uint32_t row = (uint32_t)(idx / out_width), col = (uint32_t)(idx - (size_t)row * out_width);
+    out[idx] = col < in_width ? in[(size_t)row * in_width + col] : 0.0f;
+}
+
+void launch_resize_sph_rows(hipStream_t s, uint32_t n, uint32_t in_width, uint32_t out_width, const float* in, float* out) {
+    const size_t total = (size_t)n * out_width;
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_resize_sph_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, in_width, out_width, in, out);
+}
+
 void launch_pack_activate_fields(hipStream_t s, uint32_t n, const float* pos, const float* dns, const float* rot, const float* scl,
                                  float* act12) {
     if (n == 0) return;

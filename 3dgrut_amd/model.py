@@ -8,7 +8,7 @@ import torch
 
 
 class GaussianModel(torch.nn.Module):
-    def __init__(self, scene: dict, device="cuda", sh_degree=3, background_color="black"):
+    def __init__(self, scene: dict, device="cuda", sh_degree=3, background_color="black", max_n_features=3):
         super().__init__()
         t = lambda a: torch.nn.Parameter(torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device))
         feats = np.asarray(scene["features"], np.float32)
@@ -18,13 +18,15 @@ class GaussianModel(torch.nn.Module):
         self.scale = t(np.log(np.asarray(scene["scale"], np.float64)))        # pre-activation: log-scale
         self.density = t(np.log(dens / (1 - dens)))                           # pre-activation: logit
         self.features_albedo = t(feats[:, :3])
-        self.features_specular = t(feats[:, 3:])
+        # model.py:139-154: features_specular is [N, 3 (max_n_features + 1)^2 - 3] (sh_degree_to_specular_dim); max_n_features is
+        # conf.model.progressive_training.max_n_features and must equal render.particle_radiance_sph_degree
+        self.features_specular = t(feats[:, 3:3 * (int(max_n_features) + 1) ** 2])
         # the reference's activation callables and their names (model.py:163-167, utils/misc.py:45-50, base_gs.yaml:54-55)
         self.density_activation = torch.sigmoid
         self.scale_activation = torch.exp
         self.rotation_activation = torch.nn.functional.normalize
-        self.max_n_features = 3
-        self.n_active_features = int(sh_degree)
+        self.max_n_features = int(max_n_features)
+        self.n_active_features = min(int(sh_degree), self.max_n_features)
         self.background_color = background_color
         self.device = device
 

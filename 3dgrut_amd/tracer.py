@@ -186,6 +186,9 @@ class SplatRaster:
             device_index = torch.cuda.current_device()
         self.device_index = int(device_index)
         self.enable_kernel_timings = bool(cfg.enable_kernel_timings)
+        # PARTICLE_RADIANCE_NUM_COEFFS = (degree + 1)^2 (setup_3dgut.py:48): the radiance rows are [N, 3 (degree + 1)^2]
+        self.sph_degree = int(cfg.particle_radiance_sph_degree)
+        self._radiance_width = 3 * (self.sph_degree + 1) ** 2
         _capi.check(self._lib.gut_create(C.byref(cfg), self.device_index, C.byref(self._handle)), "SplatRaster()")
         self._timings = {}
         # extension key (not in the reference's configs): render.splat.sorted_reference_backward, default true = the reference's
@@ -228,7 +231,7 @@ class SplatRaster:
         dev = ray_ori.device
         if n:
             particle_density = _check_f32_cuda(particle_density, "particleDensity", (12,))
-            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (self._radiance_width,))
         opts = dict(dtype=torch.float32, device=dev)
         rgba = torch.empty((H, W, 4), **opts)   # fully written by the kernels (no zero-fill passes)
         dist = torch.empty((H, W, 1), **opts)
@@ -265,10 +268,10 @@ class SplatRaster:
             dens_g, sph_g = out
         else:
             dens_g = torch.empty((n, 12), **opts)  # fully written by the per-Gaussian epilogue kernel
-            sph_g = torch.empty((n, 3 if compact_radiance_grads else 48), **opts)
+            sph_g = torch.empty((n, 3 if compact_radiance_grads else self._radiance_width), **opts)
         if n:
             particle_density = _check_f32_cuda(particle_density, "particleDensity", (12,))
-            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (self._radiance_width,))
         cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -301,7 +304,7 @@ class SplatRaster:
         if n:
             mog_pos = _check_f32_cuda(mog_pos, "positions", (3,)); mog_dns = _check_f32_cuda(mog_dns, "density", (1,))
             mog_rot = _check_f32_cuda(mog_rot, "rotation", (4,)); mog_scl = _check_f32_cuda(mog_scl, "scale", (3,))
-            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (self._radiance_width,))
         opts = dict(dtype=torch.float32, device=dev)
         rgba, dist, hits, vis = torch.empty((H, W, 4), **opts), torch.empty((H, W, 1), **opts), torch.empty((H, W, 1), **opts), torch.empty((n, 1), **opts)
         cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
@@ -331,9 +334,9 @@ class SplatRaster:
         dist_g = None if ray_hit_distance_grd is None else _check_f32_cuda(ray_hit_distance_grd, "rayHitDistanceGradient")
         opts = dict(dtype=torch.float32, device=dev)
         pos_g, dns_g, rot_g, scl_g = (torch.empty((n, c), **opts) for c in (3, 1, 4, 3))
-        sph_g = torch.empty((n, 48), **opts)
+        sph_g = torch.empty((n, self._radiance_width), **opts)
         if n:
-            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (48,))
+            particle_radiance = _check_f32_cuda(particle_radiance, "particleRadiance", (self._radiance_width,))
         cam = self._camera(sensor_params, ts_start, ts_end, pose_start, pose_end)
         stream = torch.cuda.current_stream(dev).cuda_stream
         ptr = lambda t: t.data_ptr() if n else None
@@ -654,6 +657,7 @@ class Tracer:
         rays_d = gpu_batch.rays_dir
         sensor, poses = Tracer.create_camera_parameters(gpu_batch)
         if (getattr(self, "split_features", True) and hasattr(self.tracer_wrapper, "trace_model_fields")
+                and getattr(self.tracer_wrapper, "sph_degree", 3) == 3   # the two-tensor hand-over is laid out for [N,3] + [N,45]
                 and hasattr(gaussians, "get_features_albedo") and hasattr(gaussians, "get_features_specular")):
             # the reference's model keeps the SH coefficients as two tensors and concatenates them for every render (model.py:74-75):
             # hand the two over as they are (the only difference from tracer.py:317-327)

@@ -64,12 +64,15 @@ typedef struct GutCamera {
 
 /* The reference bakes conf.render.* into the kernels as -D defines (setup_3dgut.py:47-70) and its
  * SplatRaster constructor reads only render.enable_kernel_timings (splatRaster.cpp:158-159).  Here
- * the same settings arrive as a struct; combinations other than the precompiled default variant
- * are rejected by gut_create with a clear message. */
+ * the same settings arrive as a struct and reach the kernels as run-time values: every key of
+ * render/3dgut.yaml may differ from its default (ut_require_all_sigma_points = true is rejected, as the
+ * reference's static_assert does).  Values the reference has no kernel for are rejected by gut_create
+ * with a clear message.  The fused optimiser entry points and the model-field traces exist for
+ * particle_radiance_sph_degree = 3 only. */
 typedef struct GutConfig {
     int32_t abi_version;                  /* GUT_ABI_VERSION */
     int32_t enable_kernel_timings;        /* render.enable_kernel_timings */
-    int32_t particle_radiance_sph_degree; /* 3  -> 16 coefficients */
+    int32_t particle_radiance_sph_degree; /* 3 -> 16 coefficients (default); 0..2: radiance rows and their gradient are [N, 3 (d+1)^2] */
     int32_t particle_kernel_degree;       /* 2 (quadratic, default); 0, 1, 3, 4, 5, 8: the reference's other generalised Gaussians */
     int32_t k_buffer_size;                /* 0 (unsorted) */
     int32_t global_z_order;               /* 1 */
@@ -137,7 +140,7 @@ void gut_destroy(gut_handle h);
 
 /* SplatRaster::trace — splatRaster.cpp:174-245.
  *   d_particle_density  f32 [N,12]  (pos3, density, quat wxyz, scale3, pad)   tracer.py:176-178
- *   d_particle_radiance f32 [N,48]  (16 SH coefficients x RGB)
+ *   d_particle_radiance f32 [N,48]  (16 SH coefficients x RGB; [N, 3 (d+1)^2] on a handle with particle_radiance_sph_degree = d < 3)
  *   d_ray_origin/d_ray_direction f32 [H,W,3] camera-space rays
  * outputs (fully written by the call, no pre-initialisation needed):
  *   d_ray_radiance_density f32 [H,W,4], d_ray_hit_distance f32 [H,W,1] (1e6 for rays that miss the

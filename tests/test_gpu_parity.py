@@ -352,6 +352,65 @@ def test_config_toggles_against_the_oracle(name, toggle):
     assert raster.stats()["traversed_bwd"] == ref["traversed_bwd"]
 
 
+@pytest.mark.parametrize("degree", [0, 1, 2])
+@pytest.mark.parametrize("name", ["c1_pinhole_128", "fisheye_distorted"])
+def test_radiance_sph_degree_below_three(name, degree):
+    """render.particle_radiance_sph_degree = d < 3 (PARTICLE_RADIANCE_NUM_COEFFS = (d + 1)^2, setup_3dgut.py:48): the radiance rows and
+    their gradient are [N, 3 (d+1)^2], the model keeps features_specular [N, 3 (d+1)^2 - 3] (model.py:139-154).  The reference reads
+    exactly that many coefficients per particle (gaussianParticles.cuh:208-216) and evaluates the active degree <= d: the oracle is
+    fed the same rows zero-extended to its 16 coefficients.  Through the whole surface (Tracer.render -> _Autograd -> backward), with
+    the usual checks; the gradient of the coefficients that do not exist must be zero in the oracle."""
+    mk, kind, W, H, (eye, tgt), kw = CASES[name]
+    sc = mk()
+    nc = (degree + 1) ** 2
+    view = make_view(kind, W, H, cams.look_at_c2w(eye, tgt), **kw)
+    model = importlib.import_module("3dgrut_amd.model").GaussianModel(sc, device=DEV, sh_degree=degree, max_n_features=degree)
+    assert model.features_specular.shape[1] == 3 * nc - 3 and model.get_features().shape[1] == 3 * nc
+    with torch.no_grad():
+        d12 = torch.cat([model.positions, model.get_density(), model.get_rotation(), model.get_scale(),
+                         torch.zeros_like(model.get_density())], 1).cpu().numpy()
+        sph = np.zeros((d12.shape[0], 48), np.float32)
+        sph[:, :3 * nc] = model.get_features().cpu().numpy()
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=degree)
+    rng = np.random.default_rng(23)
+    rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
+    dens_g, sph_g, _ = oracle.backward(view["oracle_cam"], ref, rgba_grad, np.zeros((H, W, 1), np.float32))
+    assert np.abs(sph_g[:, 3 * nc:]).max() == 0 and np.abs(sph_g[:, :3 * nc]).max() > 0
+    tr = gut.Tracer({"render": {"particle_radiance_sph_degree": degree}})
+    assert tr.tracer_wrapper.sph_degree == degree
+    out = tr.render(model, to_batch(view, DEV), train=True, frame_id=0)
+    raster = tr.tracer_wrapper
+    assert raster.stats()["num_intersections"] == ref["M"] and ref["M"] > 0
+    for key in ("tiles_count", "sorted_ids"):
+        assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
+    for key in ("proj_pos", "conic_opacity", "extent", "depth", "feat"):
+        got = raster.debug_buffer(key).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, np.ascontiguousarray(ref[key]).reshape(-1).view(np.uint32)), key
+    rgba = np.concatenate([out["pred_rgb"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
+    margins, pixel_budget = oracle.render_margins(view["oracle_cam"], ref, budget_bound=ROW_FLIP_BOUND)
+    check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"{name}/sph{degree}", budget=pixel_budget)
+    rg = torch.as_tensor(rgba_grad, device=DEV)
+    ((out["pred_rgb"][0] * rg[..., :3]).sum() + (out["pred_opacity"][0] * rg[..., 3:]).sum()).backward()
+    assert model.features_specular.grad is None or model.features_specular.grad.shape == model.features_specular.shape
+    for k, e in _activated_grads(model, dens_g, sph_g[:, :3 * nc]).items():
+        if e.size == 0:
+            continue
+        err = rel_l2(getattr(model, k).grad.cpu().numpy(), e)
+        assert err <= 2e-3, f"{name}/sph{degree}/{k}: rel L2 {err}"
+    # one more active degree than the handle has coefficients for is refused (the reference would read past its coefficient array)
+    model.n_active_features = degree + 1
+    with pytest.raises(RuntimeError, match="active SH degrees"):
+        tr.render(model, to_batch(view, DEV), train=True, frame_id=1)
+    # ... and so are the entry points that are laid out for 16 coefficients
+    batch = to_batch(view, DEV)
+    sensor, poses = gut.Tracer.create_camera_parameters(batch)
+    with pytest.raises(RuntimeError, match="particle_radiance_sph_degree"):
+        raster.trace_model_fields(0, degree, model.positions.detach(), model.get_density().detach(), model.get_rotation().detach(),
+                                  model.get_scale().detach(), model.features_albedo.detach(), torch.zeros((d12.shape[0], 45), device=DEV),
+                                  batch.rays_ori.contiguous(), batch.rays_dir.contiguous(), sensor, 0, 1, poses.T_world_sensors[0],
+                                  poses.T_world_sensors[1])
+
+
 @pytest.mark.parametrize("ulps_above", [0, 1])
 def test_fisheye_theta_equal_to_max_angle(ulps_above):
     """SURVEY §8c KAT on the device: OpenCV fisheye with non-zero polynomial coefficients and max_angle == the fp32 atan2f of a
