@@ -614,7 +614,9 @@ __global__ __launch_bounds__(kBlock, kDistGrad ? 3 : 4) void k_render_backward(V
             const float d2 = (c0 * c0 + c1 * c1 + c2 * c2) * il2;
             const float resp = kGeneral ? kernel_response(kernel_degree, d2) : fast_exp(-0.5f * d2);
             const float a0 = resp * ms.w;
-            const float alpha = fminf(c.max_alpha, a0);
+            // the literal 0.99 of processHitBwd (gaussianParticles.cuh:528), NOT render.particle_kernel_max_alpha: the reference's forward
+            // clamps with the configured value (slang particleDensityHit), its unsorted backward with this constant
+            const float alpha = fminf(0.99f, a0);
             // NB: no tmin/tmax test in the backward
             const bool hit = alive && (d2 < c.max_d2) && (resp > c.min_response) && (alpha > c.alpha_threshold);
             if (__ballot(hit) == 0ull) return;  // wave-uniform: no lane of this wave hit entry j

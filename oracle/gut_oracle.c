@@ -1191,6 +1191,14 @@ static void render_bwd_impl(const OracleParams* prm, const OracleCamera* cam, in
                        const uint32_t* ranges, const uint32_t* sorted_ids,
                        const float* rgba, const float* rgba_grad, const float* dist, const float* dist_grad,
                        double* density_grad, double* feat_grad, uint64_t* traversed_out, double* flip_budget, float flip_bound) {
+    /* The unsorted backward recomputes alpha as fminf(0.99f, gres * density) with the LITERAL 0.99 (processHitBwd,
+     * gaussianParticles.cuh:528), whatever render.particle_kernel_max_alpha is — the forward (any K) goes through the slang
+     * particleDensityHit, which clamps with GAUSSIAN_PARTICLE_MAX_ALPHA (gaussianParticles.slang:211, threedgut.slang:20).  The two agree
+     * under render/3dgut.yaml (0.99); with another max alpha the reference's backward walks a transmittance chain its forward did not,
+     * and so does this restatement. */
+    OracleParams bwd_prm = *prm;
+    bwd_prm.max_alpha = 0.99f;
+    prm = &bwd_prm;
     const PoseSet ps = make_pose_set(cam);
     const int gx = (W + GUT_TILE - 1) / GUT_TILE, gy = (H + GUT_TILE - 1) / GUT_TILE;
     uint64_t traversed_total = 0;
