@@ -13,7 +13,8 @@ step = len(sys.argv) > 3 and sys.argv[3] == "step"   # full native train steps (
 ro, rd = cams.pinhole_rays(W, H, fx, fx); K = cams.pinhole_intrinsics_dict(W, H, fx, fx)
 sc = scenes.scene_outdoor_like(n=n, seed=2)
 model = None if step else model_mod.GaussianModel(sc, device=dev)
-tr = gut.Tracer({"render": {"enable_kernel_timings": True}})
+# FWD_ONCE_KERNEL_DEGREE=n: render.particle_kernel_degree (the kGeneral compositors) instead of the default 2
+tr = gut.Tracer({"render": {"enable_kernel_timings": True, "particle_kernel_degree": int(os.environ.get("FWD_ONCE_KERNEL_DEGREE", "2"))}})
 b = gut.Batch(rays_ori=torch.as_tensor(ro, device=dev), rays_dir=torch.as_tensor(rd, device=dev),
               T_to_world=torch.as_tensor(cams.orbit_c2w(4.5, 7.0, 12.0), device=dev)[None], intrinsics_OpenCVPinholeCameraModelParameters=K)
 if step:
