@@ -49,14 +49,38 @@ def _case(seed):
     return sc, view, W, H, sh, rng
 
 
-@pytest.mark.parametrize("seed", range(16))
+def _variant(seed):
+    """seeds >= 100: the same draw of scene and camera (seed - 100) under a drawn render-config variant — one of the reference's other
+    generalised Gaussian kernels (particle_kernel_degree), sometimes other thresholds (incl. a max alpha the unsorted backward ignores,
+    gaussianParticles.cuh:528) and hit counts off."""
+    if seed < 100:
+        return {}, {}
+    rng = np.random.default_rng(7000 + seed)
+    degree = int(rng.choice([0, 1, 3, 4, 5, 8]))
+    conf, prm = {"particle_kernel_degree": degree}, {"kernel_degree": degree}
+    if rng.random() < 0.5:
+        mr, ma, mx = float(rng.choice([0.005, 0.03])), float(rng.choice([0.002, 0.01])), float(rng.choice([0.9, 0.995]))
+        conf.update(particle_kernel_min_response=mr, particle_kernel_min_alpha=ma, particle_kernel_max_alpha=mx)
+        prm.update(min_kernel_density=mr, alpha_threshold=ma, max_alpha=mx)
+    if rng.random() < 0.25:
+        conf["enable_hitcounts"] = False
+        prm["enable_hitcounts"] = 0
+    return conf, prm
+
+
+@pytest.mark.parametrize("seed", list(range(16)) + list(range(100, 112)))
 def test_random_configuration_matches_the_oracle(seed):
-    sc, view, W, H, sh, rng = _case(seed)
+    sc, view, W, H, sh, rng = _case(seed % 100)
+    conf, overrides = _variant(seed)
+    prm = oracle.default_params()
+    for k, v in overrides.items():
+        assert hasattr(prm, k), k
+        setattr(prm, k, v)
     model, d12, sph = _oracle_inputs(sc, sh)
-    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=sh)
+    ref = oracle.forward(view["oracle_cam"], W, H, d12, sph, view["ro"], view["rd"], sh_degree=sh, params=prm)
     rgba_grad = rng.normal(size=(H, W, 4)).astype(np.float32)
     dist_grad = (0.1 * rng.normal(size=(H, W, 1))).astype(np.float32) if seed % 3 == 0 else None
-    res = _run_gpu(sc, view, sh, rgba_grad=rgba_grad, dist_grad=dist_grad, model=model)
+    res = _run_gpu(sc, view, sh, rgba_grad=rgba_grad, dist_grad=dist_grad, model=model, render_conf=conf)
     raster = res["tracer"].tracer_wrapper
     for key in ("tiles_count", "tiles_offset", "unsorted_ids", "sorted_ids"):
         assert np.array_equal(raster.debug_buffer(key).cpu().numpy().view(np.uint32), ref[key]), key
@@ -68,7 +92,7 @@ def test_random_configuration_matches_the_oracle(seed):
     out = res["out"]
     rgba = np.concatenate([out["pred_rgb"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
     if ref["M"]:
-        margins, pixel_budget = oracle.render_margins(view["oracle_cam"], ref, budget_bound=ROW_FLIP_BOUND)
+        margins, pixel_budget = oracle.render_margins(view["oracle_cam"], ref, params=prm, budget_bound=ROW_FLIP_BOUND)
         # quantitative form: the ill-conditioned draws (needles, 2e-4 scales) have wide noise bands — a large share of their pixels has
         # some decision near a threshold, and each is allowed what those decisions can move it by
         check_colour_outliers(rgba, out["hits_count"][0].detach().cpu().numpy(), ref, margins, label=f"fuzz {seed}", budget=pixel_budget)
@@ -79,7 +103,7 @@ def test_random_configuration_matches_the_oracle(seed):
     if ref["M"] == 0:
         return
     dens_g, sph_g, _ = oracle.backward(view["oracle_cam"], ref, rgba_grad,
-                                       dist_grad if dist_grad is not None else np.zeros((H, W, 1), np.float32))
+                                       dist_grad if dist_grad is not None else np.zeros((H, W, 1), np.float32), params=prm)
     exp = _activated_grads(res["model"], dens_g, sph_g)
     for k, e in exp.items():
         g = getattr(res["model"], k).grad.cpu().numpy()

@@ -60,9 +60,9 @@ def _oracle_inputs(sc, sh_degree=3):
         return model, d12, model.get_features().cpu().numpy()
 
 
-def _run_gpu(sc, view, sh_degree, rgba_grad=None, dist_grad=None, timings=False, model=None, lazy=None):
+def _run_gpu(sc, view, sh_degree, rgba_grad=None, dist_grad=None, timings=False, model=None, lazy=None, render_conf=None):
     model = model if model is not None else gut_model(sc, sh_degree)
-    tr = gut.Tracer({"render": {"enable_kernel_timings": timings}})
+    tr = gut.Tracer({"render": dict(render_conf or {}, enable_kernel_timings=timings)})
     if lazy is not None:
         tr.tracer_wrapper.set_lazy_tile_order(lazy)
     batch = to_batch(view, DEV)
