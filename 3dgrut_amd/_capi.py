@@ -21,6 +21,7 @@ GRADIENT_RECORD_FLOATS = 16
 OPT_SORTED_REFERENCE_BACKWARD = 2
 OPT_EARLY_EXTRA_PERCENT = 3
 OPT_FORWARD_TILE_ORDER = 4
+OPT_KERNEL_TIMING_SET = 5
 OPT_DEBUG_REPLACE_SCRATCH = 100
 KERNEL_TIMER_NAMES = ("project", "scan", "expand", "sort", "ranges", "render", "render_bwd", "project_bwd", "optimizer",
                       "optimizer_early", "optimizer_early_2")

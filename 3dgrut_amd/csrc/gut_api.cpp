@@ -136,6 +136,9 @@ struct gut_context {
     DevBuf tiles_count, tiles_offset, proj_pos, conic_opacity, extent, depth, feat, grad16, scan_temp;
     float* stat_accum = nullptr;    // gut_set_position_gradient_statistics: consumed by the next gut_optimize_after_bwd
     int32_t* stat_denom = nullptr;
+    DevBuf wave_sums, block_prefix, scan_total;   // two-level scan of the tile counts (K1 wave sums -> k_scan_wave_sums -> K3)
+    bool timing_main_stream = true, timing_side_stream = true;   // GUT_OPT_KERNEL_TIMING_SET
+    bool dbg_offset_valid = false;                // tiles_offset (debug view only) rebuilt from tiles_count for this frame
     DevBuf sph_widened, sph_grad_wide;   // particle_radiance_sph_degree < 3: the [N,48] rows the kernels read / write
     DevBuf packed12;   // gut_trace_fields: the [N,12] rows packed from the caller's four tensors (kept for its backward)
     bool packed_valid = false;
@@ -153,6 +156,7 @@ struct gut_context {
     DevBuf ranges, trav_fwd, trav_bwd, tile_order;  // per-tile traversal depths (statistics)
     DevBuf counters;
     uint32_t* host_count = nullptr;  // pinned
+    uint32_t* host_count_dev = nullptr;   // the same words as the device addresses them (written by k_scan_wave_sums)
     hipEvent_t count_event = nullptr;  // the count read-back has landed (work queued behind it keeps the GPU busy meanwhile)
     // rows without tiles are optimised early, on a low-priority side stream under the compositing kernels
     // (gut_optimize_rows_without_gradient): ev_projected = projection AND binning of the cached forward have finished (tiles_count is
@@ -285,6 +289,15 @@ void build_consts(const GutConfig& cfg, gut::RenderConsts* c) {
                                                 : gut::kernel_cutoff_d2(cfg.particle_kernel_degree, cfg.particle_kernel_min_response) * 1.0001f + 1e-6f;
 }
 
+// None of the library's events publishes device memory to the host: they time kernels, order the library's own streams on one
+// device, or tell the host that the scan kernel has written the intersection count into COHERENT pinned memory (system-scope stores
+// of that kernel).  Without these flags every hipEventRecord makes the next dispatch wait for a system-scope cache writeback and
+// invalidation (hip_runtime_api.h: hipEventDisableSystemFence) — about 30 us per event on the 6 M-Gaussian frame, measured where the
+// count used to be copied out.
+static const bool g_event_system_fence = getenv("GUT_EVENT_SYSTEM_FENCE") != nullptr;   // A/B experiments only
+static const unsigned kTimingEvent = g_event_system_fence ? 0u : hipEventDisableSystemFence;
+static const unsigned kOrderingEvent = hipEventDisableTiming | (g_event_system_fence ? 0u : hipEventDisableSystemFence);
+
 EventPair* arm_timer(std::deque<EventPair>& q, hipStream_t s) {
     if (q.size() >= 256) {  // keep only the most recent (splatRaster.cpp:212-215)
         EventPair old = q.front();
@@ -293,7 +306,7 @@ EventPair* arm_timer(std::deque<EventPair>& q, hipStream_t s) {
         if (old.b) (void)hipEventDestroy(old.b);
     }
     EventPair p;
-    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&p.a, kTimingEvent) != hipSuccess || hipEventCreateWithFlags(&p.b, kTimingEvent) != hipSuccess) return nullptr;
     (void)hipEventRecord(p.a, s);
     q.push_back(p);
     return &q.back();
@@ -380,8 +393,10 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
     h->device = device_index;
     h->cfg = *cfg;
     build_consts(*cfg, &h->consts);
-    hipError_t e = hipHostMalloc((void**)&h->host_count, 64, hipHostMallocDefault);
+    // coherent (fine-grained) pinned words: k_scan_wave_sums stores the count here with system scope, no cache writeback needed
+    hipError_t e = hipHostMalloc((void**)&h->host_count, 64, hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) memset(h->host_count, 0, 64);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->host_count_dev, h->host_count, 0);
     if (e == hipSuccess) e = h->counters.ensure(sizeof(gut::Counters));
     if (e != hipSuccess) {
         delete h;
@@ -390,7 +405,7 @@ int gut_create(const GutConfig* cfg, int device_index, gut_handle* out) {
     if (cfg->enable_kernel_timings)
         for (auto& set : h->ring)
             for (auto& ev : set.e)
-                if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+                if (hipEventCreateWithFlags(&ev, kTimingEvent) != hipSuccess) ev = nullptr;
     *out = h;
     return 0;
 }
@@ -403,7 +418,8 @@ void gut_destroy(gut_handle h) {
     DevBuf* bufs[] = {&h->tiles_count, &h->tiles_offset, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->feat,
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
                       &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters, &h->ids_ordered,
-                      &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered, &h->wave_walked, &h->packed12, &h->walk_sums};
+                      &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered, &h->wave_walked, &h->packed12, &h->walk_sums,
+                      &h->wave_sums, &h->block_prefix, &h->scan_total, &h->sph_widened, &h->sph_grad_wide};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
@@ -486,7 +502,12 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     h->packed_valid = false;   // (gut_trace_fields sets it again once this call has succeeded)
 
     HIP_TRY(h->tiles_count.ensure(sizeof(uint32_t) * (size_t)n));
-    HIP_TRY(h->tiles_offset.ensure(sizeof(uint32_t) * (size_t)n));
+    {
+        const size_t blocks = ((size_t)n + gut::kBlock - 1) / gut::kBlock;
+        HIP_TRY(h->wave_sums.ensure(sizeof(uint32_t) * (gut::kBlock / 64) * (blocks + 1)));
+        HIP_TRY(h->block_prefix.ensure(sizeof(uint32_t) * (blocks + 1)));
+        HIP_TRY(h->scan_total.ensure(64));
+    }
     HIP_TRY(h->proj_pos.ensure(sizeof(float) * 2 * (size_t)n));
     HIP_TRY(h->conic_opacity.ensure(sizeof(float) * 4 * (size_t)n));
     HIP_TRY(h->extent.ensure(sizeof(float) * 2 * (size_t)n));
@@ -501,12 +522,11 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
         HIP_TRY(h->zero_word.ensure(64));
         HIP_TRY(hipMemsetAsync(h->zero_word.p, 0, 64, s));
     }
-    if (n) HIP_TRY(h->scan_temp.ensure(gut::scan_temp_bytes(n)));
 
-    const bool timing = h->cfg.enable_kernel_timings != 0;
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->timing_main_stream;
     EventPair* total = timing ? arm_timer(h->fwd_timers, s) : nullptr;
     h->kev_fwd_valid = false;
-    if (timing) {
+    if (h->cfg.enable_kernel_timings != 0 && (h->timing_main_stream || h->timing_side_stream)) {   // (a fresh set of events per frame)
         h->ring_cur = (h->ring_cur + 1) % gut_context::kRing;
         h->kev = h->ring[h->ring_cur].e;
         h->ring[h->ring_cur].fwd = false;
@@ -534,29 +554,33 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     gut::launch_project(s, v, h->consts, n, num_active_features, d_particle_density, d_particle_radiance,
                         h->tiles_count.as<uint32_t>(), h->proj_pos.as<float>(), h->conic_opacity.as<float>(),
                         h->extent.as<float>(), h->depth.as<float>(), h->feat.as<float>(), d_particle_visibility,
-                        h->counters.as<gut::Counters>(), d_features_albedo);
+                        h->wave_sums.as<uint32_t>(), d_features_albedo);
     mark(1);
     static const bool early_after_project = getenv("GUT_EARLY_AFTER_PROJECT") != nullptr;  // tuning experiments only
     if (early_after_project) {
-        if (!h->ev_projected) HIP_TRY(hipEventCreateWithFlags(&h->ev_projected, hipEventDisableTiming));
+        if (!h->ev_projected) HIP_TRY(hipEventCreateWithFlags(&h->ev_projected, kOrderingEvent));
         HIP_TRY(hipEventRecord(h->ev_projected, s));
     }
     const int end_bit = 32 + (int)bit_width_u32((uint32_t)tiles);
     h->dbg_sorted_valid = false;
     h->dbg_ordered_valid = false;
-    // device-side intersection count: the last element of the inclusive scan (a zero word when there are no particles)
-    const uint32_t* d_count = n ? h->tiles_offset.as<uint32_t>() + (n - 1) : h->zero_word.as<uint32_t>();
+    // device-side intersection count: written by the scan of the block sums (a zero word when there are no particles)
+    const uint32_t* d_count = n ? h->scan_total.as<uint32_t>() : h->zero_word.as<uint32_t>();
+    h->dbg_offset_valid = false;
     uint32_t m = 0;
     bool count_pending = false;
     if (n) {
-        HIP_TRY(gut::run_scan(s, h->scan_temp.p, h->scan_temp.cap, h->tiles_count.as<uint32_t>(), h->tiles_offset.as<uint32_t>(), n));
+        // K2 (gutRenderer.cu:300-311: a device-wide cub scan of the [N] counts): two levels here — K1 left one sum per wave, one
+        // workgroup scans the per-block sums (and writes the count), K3 finishes inside each wave.  One 5 us launch instead of three
+        // launches over 48 MB (0.047 ms at 6 M Gaussians).
+        gut::launch_scan_wave_sums(s, n, h->wave_sums.as<uint32_t>(), h->block_prefix.as<uint32_t>(), h->scan_total.as<uint32_t>(),
+                                   h->host_count_dev, h->walk_sums.as<uint32_t>());
         // intersection count read-back (gutRenderer.cu:313-321).  The reference blocks on it before it can size the
         // binning buffers; here the copy is queued and the host only waits for it AFTER the rest of the forward has been
         // queued against a capacity taken from the previous frames (m_capacity), so the GPU never idles on the host.
-        HIP_TRY(hipMemcpyAsync(h->host_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        // ... and with it the walked share of the last frame that had a backward (k_tile_order's walk_sums; see launch_render below)
-        if (h->walk_sums.p) HIP_TRY(hipMemcpyAsync(h->host_count + 2, h->walk_sums.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        if (!h->count_event) HIP_TRY(hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming));
+        // The scan kernel writes the count — and with it the walked share of the last frame that had a backward (k_tile_order's
+        // walk_sums; see launch_render below) — straight into the pinned host words; the event below orders the host's read.
+        if (!h->count_event) HIP_TRY(hipEventCreateWithFlags(&h->count_event, kOrderingEvent));
         HIP_TRY(hipEventRecord(h->count_event, s));
         count_pending = true;
     }
@@ -570,7 +594,8 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
             HIP_TRY(h->keys_sorted.ensure(sizeof(uint64_t) * (size_t)sort_n));
             HIP_TRY(h->ids_unsorted.ensure(sizeof(uint32_t) * (size_t)sort_n));
             HIP_TRY(h->ids_sorted.ensure(sizeof(uint32_t) * (size_t)sort_n));
-            gut::launch_expand(s, v, h->consts, n, h->tiles_offset.as<uint32_t>(), h->proj_pos.as<float>(),
+            gut::launch_expand(s, v, h->consts, n, h->tiles_count.as<uint32_t>(), h->wave_sums.as<uint32_t>(),
+                               h->block_prefix.as<uint32_t>(), h->proj_pos.as<float>(),
                                h->conic_opacity.as<float>(), h->extent.as<float>(), h->depth.as<float>(),
                                h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>(), sort_n);
             gut::launch_pad_keys(s, d_count, sort_n, h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>());
@@ -596,7 +621,7 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
         // the side-stream optimiser pass may start here: tiles_count is final and the HBM-bound part of the forward
         // (projection, scan, expansion, sort) is over — what follows on this stream is VALU-bound compositing
         if (!early_after_project) {
-            if (!h->ev_projected) HIP_TRY(hipEventCreateWithFlags(&h->ev_projected, hipEventDisableTiming));
+            if (!h->ev_projected) HIP_TRY(hipEventCreateWithFlags(&h->ev_projected, kOrderingEvent));
             HIP_TRY(hipEventRecord(h->ev_projected, s));
         }
         // with zero intersections the reference returns its freshly initialised outputs (gutRenderer.cu:323-325);
@@ -676,10 +701,8 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
         total->armed = true;
     }
     h->kev_fwd_valid = timing;
-    if (timing) {
-        h->ring[h->ring_cur].fwd = true;
-        if (h->ring_count < gut_context::kRing) h->ring_count++;
-    }
+    if (timing) h->ring[h->ring_cur].fwd = true;
+    if (h->cfg.enable_kernel_timings != 0 && (h->timing_main_stream || h->timing_side_stream) && h->ring_count < gut_context::kRing) h->ring_count++;
     h->have_forward = true;
     h->fwd_stream = s;
     h->n = n;
@@ -921,7 +944,7 @@ static int trace_bwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
         d_particle_radiance_grad = h->sph_grad_wide.as<float>();
     }
 
-    const bool timing = h->cfg.enable_kernel_timings != 0;
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->timing_main_stream;
     EventPair* total = timing ? arm_timer(h->bwd_timers, s) : nullptr;
     h->kev_bwd_valid = false;
     auto mark = [&](int i) {
@@ -1014,7 +1037,7 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
                                       (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(), h->wave_walked.as<uint8_t>());
         h->marks_valid = true;
     }
-    const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[12] && h->kev[13];
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->timing_main_stream && h->kev[12] && h->kev[13];
     if (timing) (void)hipEventRecord(h->kev[12], s);
     gut::launch_sh_adam_from_scratch(s, h->n, h->sh_degree, d_camera_position, h->grad16.as<float>(), h->tiles_count.as<uint32_t>(),
                                      h->feat.as<float>(), d_raw12, d_raw_m, d_raw_v, d_sh48, d_sh_m, d_sh_v, lr12, lr48, beta1, beta2,
@@ -1158,9 +1181,9 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
         if (pe && pe[0] == 'h') prio = greatest;
         HIP_TRY(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio));
     }
-    if (!h->ev_early_done) HIP_TRY(hipEventCreateWithFlags(&h->ev_early_done, hipEventDisableTiming));
+    if (!h->ev_early_done) HIP_TRY(hipEventCreateWithFlags(&h->ev_early_done, kOrderingEvent));
     HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_projected, 0));
-    const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[14] && h->kev[15];
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->timing_side_stream && h->kev[14] && h->kev[15];
     if (timing) (void)hipEventRecord(h->kev[14], h->side_stream);
     static int split_percent = -1;
     if (split_percent < 0) {
@@ -1201,7 +1224,7 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
 static int launch_early_part2(gut_context* h, hipStream_t s) {
     if (!h->early_part2_pending) return 0;
     h->early_part2_pending = false;
-    if (!h->ev_bwd_start) HIP_TRY(hipEventCreateWithFlags(&h->ev_bwd_start, hipEventDisableTiming));
+    if (!h->ev_bwd_start) HIP_TRY(hipEventCreateWithFlags(&h->ev_bwd_start, kOrderingEvent));
     const gut_context::EarlyArgs& ea = h->early_args;
     if (ea.extra_end) {
         // The forward compositor is done by now: mark the waves that hold a Gaussian it walked.  The backward compositor walks
@@ -1213,14 +1236,14 @@ static int launch_early_part2(gut_context* h, hipStream_t s) {
     }
     HIP_TRY(hipEventRecord(h->ev_bwd_start, s));
     HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_bwd_start, 0));
-    if (h->cfg.enable_kernel_timings != 0 && h->kev[7]) (void)hipEventRecord(h->kev[7], h->side_stream);  // start of the second launch
+    if (h->cfg.enable_kernel_timings != 0 && h->timing_side_stream && h->kev[7]) (void)hipEventRecord(h->kev[7], h->side_stream);  // start of the second launch
     gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), ea.raw12, ea.raw_m, ea.raw_v, ea.sh48,
                                            ea.sh_m, ea.sh_v, ea.lr12, ea.lr48, ea.beta1, ea.beta2, ea.eps, ea.step, ea.act12,
                                            ea.extra_end ? 0u : ea.block_begin, ea.block_end,
                                            ea.extra_end ? h->wave_walked.as<uint8_t>() : nullptr, ea.block_begin, ea.extra_end, true,
                                            gut_make_lazy(&ea.lazy, ea.step));
     HIP_TRY(hipGetLastError());
-    const bool timing = h->cfg.enable_kernel_timings != 0 && h->kev[14] && h->kev[15];
+    const bool timing = h->cfg.enable_kernel_timings != 0 && h->timing_side_stream && h->kev[14] && h->kev[15];
     if (timing) {
         (void)hipEventRecord(h->kev[15], h->side_stream);
         h->ring[h->ring_cur].early2 = h->kev[7] != nullptr;
@@ -1235,6 +1258,11 @@ int gut_set_option(gut_handle h, int32_t option, int32_t value) {
     switch (option) {
     case GUT_OPT_LAZY_TILE_ORDER: h->lazy_enabled = value != 0; return 0;
     case GUT_OPT_SORTED_REFERENCE_BACKWARD: h->sorted_reference_bwd = value != 0; return 0;
+    case GUT_OPT_KERNEL_TIMING_SET:
+        if (value < 0 || value > 2) return fail("gut_set_option: GUT_OPT_KERNEL_TIMING_SET takes 0, 1 or 2");
+        h->timing_main_stream = value == 0;
+        h->timing_side_stream = value != 2;
+        return 0;
     case GUT_OPT_FORWARD_TILE_ORDER:
         if (value < -1 || value > 1) return fail("gut_set_option: GUT_OPT_FORWARD_TILE_ORDER takes -1, 0 or 1");
         h->fwd_order_mode = value;
@@ -1370,7 +1398,18 @@ int gut_debug_buffer(gut_handle h, int32_t which, void** d_ptr, size_t* bytes) {
     const size_t n = h->n, m = h->m, t = (size_t)h->tiles;
     switch (which) {
     case GUT_BUF_TILES_COUNT: *d_ptr = h->tiles_count.p; *bytes = 4 * n; break;
-    case GUT_BUF_TILES_OFFSET: *d_ptr = h->tiles_offset.p; *bytes = 4 * n; break;
+    case GUT_BUF_TILES_OFFSET:
+        // debug view: the product path never materialises the [N] inclusive scan (see K2 in trace_fwd_impl); built here on request
+        if (!h->dbg_offset_valid && n) {
+            DeviceGuard dev_guard;
+            HIP_TRY(dev_guard.set(h->device));
+            HIP_TRY(h->tiles_offset.ensure(sizeof(uint32_t) * (size_t)n));
+            HIP_TRY(h->scan_temp.ensure(gut::scan_temp_bytes(n)));
+            HIP_TRY(gut::run_scan(h->fwd_stream, h->scan_temp.p, h->scan_temp.cap, h->tiles_count.as<uint32_t>(), h->tiles_offset.as<uint32_t>(), n));
+            HIP_TRY(hipStreamSynchronize(h->fwd_stream));
+            h->dbg_offset_valid = true;
+        }
+        *d_ptr = h->tiles_offset.p; *bytes = 4 * n; break;
     case GUT_BUF_PROJ_POSITION: *d_ptr = h->proj_pos.p; *bytes = 8 * n; break;
     case GUT_BUF_CONIC_OPACITY: *d_ptr = h->conic_opacity.p; *bytes = 16 * n; break;
     case GUT_BUF_PROJ_EXTENT: *d_ptr = h->extent.p; *bytes = 8 * n; break;

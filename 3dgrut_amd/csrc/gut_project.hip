@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, Re
                                                             uint32_t* __restrict__ tiles_count, float2* __restrict__ proj_pos,
                                                             float4* __restrict__ conic_opacity, float2* __restrict__ extent,
                                                             float* __restrict__ depth, float* __restrict__ feat,
-                                                            float* __restrict__ visibility, Counters* __restrict__ counters) {
+                                                            float* __restrict__ visibility, uint32_t* __restrict__ wave_sums) {
     __shared__ float sh_lds[(kBlock / 64) * 32 * kShRow];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = (int)(threadIdx.x & 63);
@@ -615,7 +615,78 @@ __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, Re
     }
     // NB: no global "visible" counter here — 94 k same-address atomics cost ~1 ms at N = 6 M (they serialise at the
     // memory side).  V is counted on demand from tiles_count (k_stats_reduce, gut_get_stats).
-    (void)counters;
+    // K2, first level: the tile count of this wave's 64 Gaussians (every wave of the grid writes one, zero beyond n) — a block's four sums
+    // are one uint4.  k_scan_wave_sums turns them into per-block offsets, k_expand_tiles finishes the scan inside each wave: the
+    // reference's (and rounds 1-3's) device-wide inclusive scan of the [N] counts (gutRenderer.cu:300-311: cub) is gone from the frame.
+    {
+        uint32_t wsum = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, o);
+        if (lane == 0) wave_sums[blockIdx.x * (kBlock / 64) + (uint32_t)wave] = wsum;
+    }
+}
+
+// K2, second level: exclusive scan of the per-256-row-block sums (one uint4 of wave sums per block) by ONE workgroup — 23 k values at
+// 6 M Gaussians, one iteration — and the frame's intersection count.  block_prefix[b] = list entries of all Gaussians before
+// block b; *total = M.
+// host_out (pinned host memory, may be null): [0] = M, [2], [3] = walk_sums of the last frame that had a backward — what the host reads
+// once it has queued the rest of the frame; written from here instead of by two stream-ordered 4- and 8-byte copies (~12 us each).
+__global__ __launch_bounds__(1024) void k_scan_wave_sums(const uint4* __restrict__ wave_sums4, uint32_t nblocks,
+                                                         uint32_t* __restrict__ block_prefix, uint32_t* __restrict__ total,
+                                                         uint32_t* __restrict__ host_out, const uint32_t* __restrict__ walk_sums) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_carry = 0u;
+    __syncthreads();
+    constexpr uint32_t kPer = 24;  // consecutive blocks per thread: 6.29 M Gaussians per iteration (one load latency, one scan)
+    for (uint32_t base = 0; base < nblocks; base += 1024u * kPer) {
+        uint32_t local[kPer];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t b = base + tid * kPer + k;
+            uint32_t v = 0;
+            if (b < nblocks) {
+                const uint4 w = wave_sums4[b];
+                v = w.x + w.y + w.z + w.w;
+            }
+            local[k] = sum;
+            sum += v;
+        }
+        uint32_t incl = sum;   // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if ((int)lane >= o) incl += up;
+        }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_excl = 0, iter_total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t t = s_wave[w];
+            if (w < wave) wave_excl += t;
+            iter_total += t;
+        }
+        const uint32_t excl = s_carry + wave_excl + (incl - sum);
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t b = base + tid * kPer + k;
+            if (b < nblocks) block_prefix[b] = excl + local[k];
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += iter_total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *total = s_carry;
+        if (host_out) {
+            host_out[0] = s_carry;
+            if (walk_sums) { host_out[2] = walk_sums[0]; host_out[3] = walk_sums[1]; }
+            __threadfence_system();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -623,7 +694,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, Re
 // path writes in the same row-major tile order (ballot prefix), so the unsorted buffers are identical.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderConsts c, uint32_t n,
-                                                        const uint32_t* __restrict__ offset,
+                                                        const uint32_t* __restrict__ tiles_count,
+                                                        const uint4* __restrict__ wave_sums4,
+                                                        const uint32_t* __restrict__ block_prefix,
                                                         const float2* __restrict__ proj_pos,
                                                         const float4* __restrict__ conic_opacity,
                                                         const float2* __restrict__ extent, const float* __restrict__ depth,
@@ -640,15 +713,27 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
     float max_power = 0.f;
     TileBox bb = {0, 0, 0, 0};
     int area = 0;
+    uint32_t my_cnt = 0;
     if (i < n) {
         e = extent[i];
         active = !(e.x <= 1e-06f);
+        my_cnt = tiles_count[i];
     }
+    // K2, third level: this Gaussian's first list slot = entries of the blocks before this one (k_scan_wave_sums) + of the waves before
+    // this one in the block (K1's wave sums) + of the lanes before this one (scan over the wave)
+    uint32_t incl = my_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += up;
+    }
+    const uint4 ws = wave_sums4[blockIdx.x];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t first = block_prefix[blockIdx.x] + (wv > 0u ? ws.x : 0u) + (wv > 1u ? ws.y : 0u) + (wv > 2u ? ws.z : 0u) + (incl - my_cnt);
     if (active) {
         dkey = f2u(depth[i]);
-        off = (i == 0) ? 0u : offset[i - 1];
-        max_off = min(offset[i], capacity);
-        off = min(off, max_off);
+        max_off = min(first + my_cnt, capacity);
+        off = min(first, max_off);
         p = proj_pos[i];
         bb = tile_bbox(v.grid_x, v.grid_y, p.x, p.y, e.x, e.y);
         area = (bb.x1 - bb.x0) * (bb.y1 - bb.y0);
@@ -981,7 +1066,7 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock
 void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, int sh_degree,
                     const float* density12, const float* sph48, uint32_t* tiles_count, float* proj_pos,
                     float* conic_opacity, float* extent, float* depth, float* feat, float* visibility,
-                    Counters* counters, const float* sph_albedo) {
+                    uint32_t* wave_sums, const float* sph_albedo) {
     if (n == 0) return;
     bool distorted = false;
     for (float k : v.radial) distorted |= (k != 0.0f);
@@ -997,14 +1082,23 @@ void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, u
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), sph48, sph_albedo, tiles_count, reinterpret_cast<float2*>(proj_pos),
                        reinterpret_cast<float4*>(conic_opacity), reinterpret_cast<float2*>(extent), depth, feat, visibility,
-                       counters);
+                       wave_sums);
 }
 
-void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* offset,
+void launch_scan_wave_sums(hipStream_t s, uint32_t n, const uint32_t* wave_sums, uint32_t* block_prefix, uint32_t* total,
+                           uint32_t* host_out, const uint32_t* walk_sums) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_scan_wave_sums, dim3(1), dim3(1024), 0, s, reinterpret_cast<const uint4*>(wave_sums), blocks_for(n), block_prefix,
+                       total, host_out, walk_sums);
+}
+
+void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* tiles_count,
+                   const uint32_t* wave_sums, const uint32_t* block_prefix,
                    const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
                    uint64_t* keys, uint32_t* ids, uint32_t capacity) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_expand_tiles, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, offset,
+    hipLaunchKernelGGL(k_expand_tiles, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, tiles_count,
+                       reinterpret_cast<const uint4*>(wave_sums), block_prefix,
                        reinterpret_cast<const float2*>(proj_pos), reinterpret_cast<const float4*>(conic_opacity),
                        reinterpret_cast<const float2*>(extent), depth, keys, ids, capacity);
 }

@@ -503,6 +503,11 @@ class SplatRaster:
         the share of their lists the last frames walked (GUT_OPT_FORWARD_TILE_ORDER, gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_FORWARD_TILE_ORDER, int(mode)), "set_option")
 
+    def set_kernel_timing_set(self, which):
+        """With enable_kernel_timings: 0 = every kernel boundary of the following frames is bracketed by events, 2 = none, 1 = only the
+        side-stream optimiser launches (GUT_OPT_KERNEL_TIMING_SET, gut_hip.h)."""
+        _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_KERNEL_TIMING_SET, int(which)), "set_option")
+
     def debug_replace_scratch(self, index):
         """Developer probe: move one of the handle's scratch buffers to a fresh allocation (GUT_OPT_DEBUG_REPLACE_SCRATCH, gut_hip.h)."""
         _capi.check(self._lib.gut_set_option(self._handle, _capi.OPT_DEBUG_REPLACE_SCRATCH, int(index)), "set_option")

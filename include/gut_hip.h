@@ -278,6 +278,13 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * share of their lists the last frames walked (longest first above 25 %: then the length of a list says how long its tile will
  * run; read back with the intersection count, no extra synchronisation).  Results do not depend on it. */
 #define GUT_OPT_FORWARD_TILE_ORDER 4
+/* GUT_OPT_KERNEL_TIMING_SET (default 0; only with enable_kernel_timings): which kernel boundaries of the following frames are
+ * bracketed by events.  0 = all of them; 2 = none (as with enable_kernel_timings = 0, switchable at run time: bench.py times its
+ * steps this way and collects the per-kernel times in a second pass — the two dozen event records per train step cost 5 - 7 % of
+ * a 2.4 ms step on MI355X); 1 = only the optimiser launches on the library's side stream (measured: SLOWER than either, the side
+ * stream's second launch takes 1.7 instead of 1.1 ms when the caller's stream carries no events — kept for experiments).  Timers of
+ * boundaries that were not bracketed read -1. */
+#define GUT_OPT_KERNEL_TIMING_SET 5
 #define GUT_OPT_DEBUG_REPLACE_SCRATCH 100
 int gut_set_option(gut_handle h, int32_t option, int32_t value);
 
