@@ -9,7 +9,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "round3"
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 # (regex on the demangled kernel name, bench key).  Templated names: k_render<true>(, k_render_backward<false>(, k_sh_adam<true>(
-KEYS = [(r"\bk_project_on_tiles\b", "project"), (r"\bk_expand_tiles\b", "expand"), (r"\bk_tile_ranges\b", "ranges"),
+KEYS = [(r"\bk_project_on_tiles\b", "project"), (r"\bk_scan_wave_sums\b", "scan"), (r"\bk_expand_tiles\b", "expand"), (r"\bk_tile_ranges\b", "ranges"),
         (r"\bk_render(<[^>]*>)?\(", "render"), (r"\bk_render_backward\b", "render_bwd"), (r"\bk_project_backward", "project_bwd"),
         (r"\bk_sh_adam\b", "optimizer"), (r"\bk_adam_rows_without_gradient\b", "optimizer_early"), (r"onesweep|radix_sort|OneSweep", "sort"),
         (r"\bk_ssim_|k_photometric", "loss")]
@@ -173,7 +173,7 @@ for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimize
              f"{g(e, 'SQ_INSTS_LDS', '{:.3e}')} | {g(e, 'SQ_LDS_BANK_CONFLICT', '{:.3e}')} | {g(e, 'atomic_GBps', '{:.0f}')} |")
 L += ["", "`optimizer_early` is the side-stream optimiser kernel, launched twice per step: its row is the step's total (both launches, "
           "run alone here because the PMC passes serialise the kernels), `optimizer_early_2` the second launch.",
-      "", "Top kernels (all launches of the run: 25 train steps + 10 render-only frames + setup):\n",
+      "", "Top kernels (all launches of the run: warm-up, the 20 timed and the 20 instrumented train steps, 10 render-only frames, the drop-in legs, setup):\n",
       "| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|"]
 for r in rows[:18]:
     L.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
