@@ -539,8 +539,19 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
         if (timing && h->kev[i]) (void)hipEventRecord(h->kev[i], s);
     };
 
-    HIP_TRY(hipMemsetAsync(h->trav_bwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
-    HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
+    // per-tile ranges / backward traversal depths and the per-wave "walked" bytes start every frame at zero: K1 clears them on its way
+    // (three fill launches on the step's critical chain until round 4); without Gaussians there is no K1
+    gut::FrameClears clears;
+    clears.ranges = h->ranges.as<uint2>();
+    clears.trav_bwd = h->trav_bwd.as<uint32_t>();
+    clears.tiles = (uint32_t)tiles;
+    if (n) {
+        HIP_TRY(h->wave_walked.ensure(((size_t)n + gut::kBlock - 1) / gut::kBlock * (gut::kBlock / 64) + 64));
+        clears.wave_walked = h->wave_walked.as<uint8_t>();
+    } else {
+        HIP_TRY(hipMemsetAsync(h->trav_bwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
+        HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
+    }
     mark(0);
     if (h->cfg.particle_radiance_sph_degree != 3 && n) {
         // rows of 3 (degree + 1)^2 floats (gaussianParticles.cuh:208-216 reads PARTICLE_RADIANCE_NUM_COEFFS coefficients per particle):
@@ -554,7 +565,7 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     gut::launch_project(s, v, h->consts, n, num_active_features, d_particle_density, d_particle_radiance,
                         h->tiles_count.as<uint32_t>(), h->proj_pos.as<float>(), h->conic_opacity.as<float>(),
                         h->extent.as<float>(), h->depth.as<float>(), h->feat.as<float>(), d_particle_visibility,
-                        h->wave_sums.as<uint32_t>(), d_features_albedo);
+                        h->wave_sums.as<uint32_t>(), d_features_albedo, clears);
     mark(1);
     static const bool early_after_project = getenv("GUT_EARLY_AFTER_PROJECT") != nullptr;  // tuning experiments only
     if (early_after_project) {
@@ -595,10 +606,9 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
             HIP_TRY(h->ids_unsorted.ensure(sizeof(uint32_t) * (size_t)sort_n));
             HIP_TRY(h->ids_sorted.ensure(sizeof(uint32_t) * (size_t)sort_n));
             gut::launch_expand(s, v, h->consts, n, h->tiles_count.as<uint32_t>(), h->wave_sums.as<uint32_t>(),
-                               h->block_prefix.as<uint32_t>(), h->proj_pos.as<float>(),
+                               h->block_prefix.as<uint32_t>(), d_count, h->proj_pos.as<float>(),
                                h->conic_opacity.as<float>(), h->extent.as<float>(), h->depth.as<float>(),
                                h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>(), sort_n);
-            gut::launch_pad_keys(s, d_count, sort_n, h->keys_unsorted.as<uint64_t>(), h->ids_unsorted.as<uint32_t>());
             mark(3);
             if (lazy) {
                 HIP_TRY(h->sort_temp.ensure(gut::sort_tiles_temp_bytes(sort_n, end_bit)));
@@ -1031,8 +1041,7 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
     // Gaussian of the wave among the entries the forward walked (unsorted variant).  The marks exist already when the side
     // stream's second launch built them; otherwise (one-pass step) they are built here.
     if (lz.wave_step && h->cfg.k_buffer_size == 0 && h->m && !h->marks_valid) {
-        HIP_TRY(h->wave_walked.ensure(((size_t)h->n + 63) / 64));
-        HIP_TRY(hipMemsetAsync(h->wave_walked.p, 0, ((size_t)h->n + 63) / 64, s));
+        // (the bytes are zero: K1 cleared them at the start of this frame and nothing has marked them since — marks_valid)
         gut::launch_mark_walked_waves(s, h->n, (uint32_t)h->tiles, h->ranges.as<uint32_t>(), h->trav_fwd.as<uint32_t>(),
                                       (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(), h->wave_walked.as<uint8_t>());
         h->marks_valid = true;
@@ -1208,7 +1217,7 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     // unsorted variant with something to walk: the second launch also takes, in the first early_extra_percent of the blocks,
     // the waves with tiles in which the forward walked no Gaussian (see launch_early_part2)
     ea.extra_end = (h->cfg.k_buffer_size == 0 && h->m) ? (uint32_t)((uint64_t)nblocks * (uint32_t)h->early_extra_percent / 100u) : 0u;
-    if (ea.extra_end) HIP_TRY(h->wave_walked.ensure(((size_t)h->n + 63) / 64));
+    // (wave_walked was sized and cleared by the forward)
     h->early_part2_pending = first < nblocks || ea.extra_end > 0;
     if (timing) {
         (void)hipEventRecord(h->kev[15], h->side_stream);  // re-recorded behind the second launch
@@ -1229,7 +1238,7 @@ static int launch_early_part2(gut_context* h, hipStream_t s) {
     if (ea.extra_end) {
         // The forward compositor is done by now: mark the waves that hold a Gaussian it walked.  The backward compositor walks
         // no further than the forward did (it is bounded by the forward's per-tile depth), so every other wave is gradient-free.
-        HIP_TRY(hipMemsetAsync(h->wave_walked.p, 0, ((size_t)h->n + 63) / 64, s));
+        // (zero since K1 of this frame)
         gut::launch_mark_walked_waves(s, h->n, (uint32_t)h->tiles, h->ranges.as<uint32_t>(), h->trav_fwd.as<uint32_t>(),
                                       (h->lazy_order ? h->ids_ordered : h->ids_sorted).as<uint32_t>(), h->wave_walked.as<uint8_t>());
         h->marks_valid = true;

@@ -86,16 +86,26 @@ struct LazyMoments {
     uint32_t* overrun = nullptr;   // GutLazyMoments.d_overrun
 };
 
+// what K1 zeroes on its way (the frame's small clears): ranges [tiles] uint2, trav_bwd [tiles], wave_walked [4 * blocks] bytes (or null)
+struct FrameClears {
+    uint2* ranges = nullptr;
+    uint32_t* trav_bwd = nullptr;
+    uint8_t* wave_walked = nullptr;
+    uint32_t tiles = 0;
+};
+
 // ---- launch wrappers implemented in the .hip files -------------------------------------------------
 void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, int sh_degree,
                     const float* density12, const float* sph48, uint32_t* tiles_count, float* proj_pos,
                     float* conic_opacity, float* extent, float* depth, float* feat, float* visibility,
-                    uint32_t* wave_sums /* [4 * blocks]: tile count of every 64-row wave (first level of the scan) */, const float* sph_albedo = nullptr /* non-null: sph48 is features_specular [N,45], this is features_albedo [N,3] */);
+                    uint32_t* wave_sums /* [4 * blocks]: tile count of every 64-row wave (first level of the scan) */, const float* sph_albedo /* non-null: sph48 is features_specular [N,45], this is features_albedo [N,3] */,
+                    const FrameClears& clears);
 // second level of the scan of the tile counts: block_prefix[b] = list entries of the Gaussians before 256-row block b, *total = M
 void launch_scan_wave_sums(hipStream_t s, uint32_t n, const uint32_t* wave_sums, uint32_t* block_prefix, uint32_t* total,
                            uint32_t* host_out /* device view of pinned host words, or null */, const uint32_t* walk_sums /* or null */);
 void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* tiles_count,
-                   const uint32_t* wave_sums, const uint32_t* block_prefix, const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
+                   const uint32_t* wave_sums, const uint32_t* block_prefix, const uint32_t* total /* device word: M; the tail
+                   [M, capacity) of keys / ids is padded here */, const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
                    uint64_t* keys, uint32_t* ids, uint32_t capacity);
 void launch_pad_keys(hipStream_t s, const uint32_t* count, uint32_t sort_n, uint64_t* keys, uint32_t* ids);
 // debug view only: ordered_ids[range.x + tile_ordered[t] .. range.y) := padding id for every tile t

@@ -352,11 +352,18 @@ __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, Re
                                                             uint32_t* __restrict__ tiles_count, float2* __restrict__ proj_pos,
                                                             float4* __restrict__ conic_opacity, float2* __restrict__ extent,
                                                             float* __restrict__ depth, float* __restrict__ feat,
-                                                            float* __restrict__ visibility, uint32_t* __restrict__ wave_sums) {
+                                                            float* __restrict__ visibility, uint32_t* __restrict__ wave_sums,
+                                                            FrameClears clr) {
     __shared__ float sh_lds[(kBlock / 64) * 32 * kShRow];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)(threadIdx.x >> 6);
+    // the frame's small clears (three fill launches until round 4): per-tile ranges and backward traversal depths, one byte per wave
+    for (uint32_t t = i; t < clr.tiles; t += gridDim.x * kBlock) {
+        clr.ranges[t] = make_uint2(0u, 0u);
+        clr.trav_bwd[t] = 0u;
+    }
+    if (lane == 0 && clr.wave_walked) clr.wave_walked[blockIdx.x * (kBlock / 64) + (uint32_t)wave] = 0;
     uint32_t cnt = 0;
     bool conic_ok = false, ok = false;
     float cx = 0.f, cy = 0.f, con0 = 0.f, con1 = 0.f, con2 = 0.f, con3 = 0.f, ex = 0.f, ey = 0.f, zkey = 0.f;
@@ -697,6 +704,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
                                                         const uint32_t* __restrict__ tiles_count,
                                                         const uint4* __restrict__ wave_sums4,
                                                         const uint32_t* __restrict__ block_prefix,
+                                                        const uint32_t* __restrict__ total,
                                                         const float2* __restrict__ proj_pos,
                                                         const float4* __restrict__ conic_opacity,
                                                         const float2* __restrict__ extent, const float* __restrict__ depth,
@@ -706,6 +714,18 @@ __global__ __launch_bounds__(kBlock) void k_expand_tiles(ViewParams v, RenderCon
     // here and the host, which reads the count once everything is queued, grows the buffers and redoes the binning.
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = (int)(threadIdx.x & 63);
+    {
+        // Padding behind the last real entry (a separate launch until round 4): the sort runs over `capacity` >= M slots (sized on the
+        // host before M is known), the tail [M, capacity) carries the reference's padding pair (gutProjector.cuh:372-376), which sorts
+        // behind every tile.  Every workgroup fills one slice of the tail.
+        const uint32_t m = min(*total, capacity);
+        const uint32_t per = (capacity - m + gridDim.x - 1) / gridDim.x;
+        const uint32_t beg = m + blockIdx.x * per, end = min(beg + per, capacity);
+        for (uint32_t k = beg + threadIdx.x; k < end; k += kBlock) {
+            keys[k] = ((uint64_t)kInvalid << 32) | f2u(3.4028235e+38f);
+            ids[k] = kInvalid;
+        }
+    }
     bool active = false;
     float2 e = make_float2(0.f, 0.f), p = make_float2(0.f, 0.f);
     float4 con = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1066,7 +1086,7 @@ static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock
 void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, int sh_degree,
                     const float* density12, const float* sph48, uint32_t* tiles_count, float* proj_pos,
                     float* conic_opacity, float* extent, float* depth, float* feat, float* visibility,
-                    uint32_t* wave_sums, const float* sph_albedo) {
+                    uint32_t* wave_sums, const float* sph_albedo, const FrameClears& clears) {
     if (n == 0) return;
     bool distorted = false;
     for (float k : v.radial) distorted |= (k != 0.0f);
@@ -1082,7 +1102,7 @@ void launch_project(hipStream_t s, const ViewParams& v, const RenderConsts& c, u
     hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, sh_degree,
                        reinterpret_cast<const float4*>(density12), sph48, sph_albedo, tiles_count, reinterpret_cast<float2*>(proj_pos),
                        reinterpret_cast<float4*>(conic_opacity), reinterpret_cast<float2*>(extent), depth, feat, visibility,
-                       wave_sums);
+                       wave_sums, clears);
 }
 
 void launch_scan_wave_sums(hipStream_t s, uint32_t n, const uint32_t* wave_sums, uint32_t* block_prefix, uint32_t* total,
@@ -1093,12 +1113,12 @@ void launch_scan_wave_sums(hipStream_t s, uint32_t n, const uint32_t* wave_sums,
 }
 
 void launch_expand(hipStream_t s, const ViewParams& v, const RenderConsts& c, uint32_t n, const uint32_t* tiles_count,
-                   const uint32_t* wave_sums, const uint32_t* block_prefix,
+                   const uint32_t* wave_sums, const uint32_t* block_prefix, const uint32_t* total,
                    const float* proj_pos, const float* conic_opacity, const float* extent, const float* depth,
                    uint64_t* keys, uint32_t* ids, uint32_t capacity) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_expand_tiles, dim3(blocks_for(n)), dim3(kBlock), 0, s, v, c, n, tiles_count,
-                       reinterpret_cast<const uint4*>(wave_sums), block_prefix,
+                       reinterpret_cast<const uint4*>(wave_sums), block_prefix, total,
                        reinterpret_cast<const float2*>(proj_pos), reinterpret_cast<const float4*>(conic_opacity),
                        reinterpret_cast<const float2*>(extent), depth, keys, ids, capacity);
 }
