@@ -696,7 +696,7 @@ def main():
                                      record_capacity_overflows=getattr(getattr(stepper, "_exchange", None), "overflows", None),
                                      replica_check="checksums of parameters and moments MIN/MAX-reduced on step 0 (passed, or this line would not exist)",
                                      hardware_status="the N > 1 path has run on multi-GPU hardware only in the driver's own scaling runs; "
-                                                     "builder-side it is covered by gloo world-2/3 tests and two-process one-GPU tests")
+                                                     "builder-side it is covered by gloo world-2/3 tests, a world-8 gloo test of the record exchange and two-process one-GPU tests")
         out["config"]["warmup_extended_by"] = res.get("extra_warmup", 0)
         if world == 1 and not args.no_drop_in and args.trainer == "native":
             try:
