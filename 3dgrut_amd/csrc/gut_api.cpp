@@ -136,6 +136,7 @@ struct gut_context {
     DevBuf tiles_count, tiles_offset, proj_pos, conic_opacity, extent, depth, feat, grad16, scan_temp;
     float* stat_accum = nullptr;    // gut_set_position_gradient_statistics: consumed by the next gut_optimize_after_bwd
     int32_t* stat_denom = nullptr;
+    DevBuf cam_pos;   // [3] floats: the sensor position of the cached forward (written by K1)
     DevBuf wave_sums, block_prefix, scan_total;   // two-level scan of the tile counts (K1 wave sums -> k_scan_wave_sums -> K3)
     bool timing_main_stream = true, timing_side_stream = true;   // GUT_OPT_KERNEL_TIMING_SET
     bool dbg_offset_valid = false;                // tiles_offset (debug view only) rebuilt from tiles_count for this frame
@@ -419,7 +420,7 @@ void gut_destroy(gut_handle h) {
                       &h->grad16, &h->scan_temp, &h->keys_unsorted, &h->keys_sorted, &h->ids_unsorted, &h->ids_sorted,
                       &h->sort_temp, &h->ranges, &h->trav_fwd, &h->trav_bwd, &h->tile_order, &h->counters, &h->ids_ordered,
                       &h->dbg_keys_sorted, &h->dbg_ids_sorted, &h->zero_word, &h->tile_ordered, &h->wave_walked, &h->packed12, &h->walk_sums,
-                      &h->wave_sums, &h->block_prefix, &h->scan_total, &h->sph_widened, &h->sph_grad_wide};
+                      &h->wave_sums, &h->block_prefix, &h->scan_total, &h->sph_widened, &h->sph_grad_wide, &h->cam_pos};
     for (DevBuf* b : bufs) b->release();
     if (h->host_count) (void)hipHostFree(h->host_count);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
@@ -548,6 +549,8 @@ static int trace_fwd_impl(gut_handle h, void* stream_, uint32_t frame_number, in
     if (n) {
         HIP_TRY(h->wave_walked.ensure(((size_t)n + gut::kBlock - 1) / gut::kBlock * (gut::kBlock / 64) + 64));
         clears.wave_walked = h->wave_walked.as<uint8_t>();
+        HIP_TRY(h->cam_pos.ensure(64));
+        clears.cam_pos = h->cam_pos.as<float>();
     } else {
         HIP_TRY(hipMemsetAsync(h->trav_bwd.p, 0, sizeof(uint32_t) * (size_t)tiles, s));
         HIP_TRY(hipMemsetAsync(h->ranges.p, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s));
@@ -1026,8 +1029,9 @@ int gut_optimize_after_bwd(gut_handle h, void* stream_, int32_t num_active_featu
         return fail("gut_optimize_after_bwd: no backward context on this stream (call gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) first)");
     if (num_active_features != h->sh_degree) return fail("gut_optimize_after_bwd: sh degree differs from the cached forward");
     if (h->n == 0) return 0;
-    if (!d_camera_position || !d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48)
+    if (!d_raw12 || !d_raw_m || !d_raw_v || !d_sh48 || !d_sh_m || !d_sh_v || !lr12 || !lr48)
         return fail("gut_optimize_after_bwd: null pointer argument");
+    if (!d_camera_position) d_camera_position = h->cam_pos.as<float>();   // the cached forward's own sensor position (K1 left it there)
     if (h->early_ran && d_visibility)
         return fail("gut_optimize_after_bwd: a visibility mask cannot follow gut_optimize_rows_without_gradient");
     DeviceGuard dev_guard;

@@ -92,6 +92,7 @@ struct FrameClears {
     uint32_t* trav_bwd = nullptr;
     uint8_t* wave_walked = nullptr;
     uint32_t tiles = 0;
+    float* cam_pos = nullptr;   // [3]: K1 also leaves the sensor position (ViewParams.s2w.t) on the device
 };
 
 // ---- launch wrappers implemented in the .hip files -------------------------------------------------

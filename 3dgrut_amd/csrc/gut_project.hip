@@ -364,6 +364,11 @@ __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, Re
         clr.trav_bwd[t] = 0u;
     }
     if (lane == 0 && clr.wave_walked) clr.wave_walked[blockIdx.x * (kBlock / 64) + (uint32_t)wave] = 0;
+    // ... and the sensor position the view-dependent colours below are evaluated from, for the fused optimiser's SH gradient
+    // (gut_optimize_after_bwd with a null camera position): the same three floats in both passes, no host-to-device copy in the step
+    if (i == 0 && clr.cam_pos) {
+        clr.cam_pos[0] = v.s2w.t[0]; clr.cam_pos[1] = v.s2w.t[1]; clr.cam_pos[2] = v.s2w.t[2];
+    }
     uint32_t cnt = 0;
     bool conic_ok = false, ok = false;
     float cx = 0.f, cy = 0.f, con0 = 0.f, con1 = 0.f, con2 = 0.f, con3 = 0.f, ex = 0.f, ey = 0.f, zkey = 0.f;
@@ -689,9 +694,14 @@ __global__ __launch_bounds__(1024) void k_scan_wave_sums(const uint4* __restrict
     if (tid == 0) {
         *total = s_carry;
         if (host_out) {
-            host_out[0] = s_carry;
-            if (walk_sums) { host_out[2] = walk_sums[0]; host_out[3] = walk_sums[1]; }
-            __threadfence_system();
+            // system-scope stores into coherent host memory: they bypass the caches, and the end of the kernel orders them before the
+            // event the host waits on.  (NOT __threadfence_system(): on gfx950 that writes back the whole L2 — dirty from K1 — and made
+            // this kernel 28 us long.)
+            __hip_atomic_store(&host_out[0], s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (walk_sums) {
+                __hip_atomic_store(&host_out[2], walk_sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&host_out[3], walk_sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

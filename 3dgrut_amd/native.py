@@ -623,7 +623,9 @@ class NativeTrainStep:
                 stats = self.fused_statistics() if self.fused_statistics is not None else None
                 if stats is not None:
                     self.raster.set_position_gradient_statistics(*stats)
-                self.raster.optimize_after_bwd(m.n_active_features, self._sensor_position(batch), m.raw, self.m12, self.v12, m.features,
+                # camera position None: the library uses the sensor position of its cached forward (the very floats K1 evaluated the
+                # colours from; an 18 us host-to-device copy sat here, between K7 and the pass over the walked waves, until round 4)
+                self.raster.optimize_after_bwd(m.n_active_features, None, m.raw, self.m12, self.v12, m.features,
                                                self.m48, self.v48, self.lr12, self.lr48, self.betas, self.eps,
                                                0 if self.selective else self.step_id + 1, vmask, self.act, lazy=self._lazy())
                 self._act_key = (m.raw.data_ptr(), m.raw._version, m.raw.shape[0])

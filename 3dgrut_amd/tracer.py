@@ -435,11 +435,13 @@ class SplatRaster:
     def optimize_after_bwd(self, num_active_features, camera_position, raw12, raw_m, raw_v, sh48, sh_m, sh_v, lr12, lr48, betas, eps,
                            step, visibility=None, act_out=None, lazy=None):
         """Per-Gaussian backward epilogue + SH-gradient rebuild + Adam in one pass (gut_optimize_after_bwd); follows a
-        trace_bwd(..., skip_epilogue=True) on the same stream.  lr12 / lr48: float32 numpy arrays."""
+        trace_bwd(..., skip_epilogue=True) on the same stream.  lr12 / lr48: float32 numpy arrays.  camera_position None: the sensor
+        position of the cached forward, which the library keeps on the device (no host-to-device copy in the step)."""
         f32p = C.POINTER(C.c_float)
         stream = torch.cuda.current_stream(raw12.device).cuda_stream
         with torch.cuda.device(raw12.device):
-            rc = self._lib.gut_optimize_after_bwd(self._handle, C.c_void_p(stream), int(num_active_features), camera_position.data_ptr(),
+            rc = self._lib.gut_optimize_after_bwd(self._handle, C.c_void_p(stream), int(num_active_features),
+                                                  None if camera_position is None else camera_position.data_ptr(),
                                                   raw12.data_ptr(), raw_m.data_ptr(), raw_v.data_ptr(), sh48.data_ptr(), sh_m.data_ptr(),
                                                   sh_v.data_ptr(), lr12.ctypes.data_as(f32p), lr48.ctypes.data_as(f32p), betas[0],
                                                   betas[1], eps, int(step), None if visibility is None else visibility.data_ptr(),

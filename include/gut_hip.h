@@ -387,7 +387,8 @@ int gut_sh_adam_step(void* stream, uint32_t num_particles, int32_t sh_degree, ui
 /* Epilogue of the last gut_trace_bwd_ex(..., GUT_BWD_SKIP_EPILOGUE) + gut_sh_adam_step for ONE view in a single kernel:
  * chains the handle's gradient rows to the raw parameters (sigmoid / normalise / exp recomputed from d_raw12, which must be
  * the rows the forward's gut_activate_pack input was made from), rebuilds the SH gradient from the masked dL/dRGB and
- * applies Adam to d_raw12 / d_sh48.  d_camera_position: device [3] sensor position of the view.  Other arguments as in
+ * applies Adam to d_raw12 / d_sh48.  d_camera_position: device [3] sensor position of the view, or NULL = the sensor position of
+ * the cached forward, which the library keeps on the device (the floats its projection evaluated the colours from).  Other arguments as in
  * gut_sh_adam_step.  Consumes the backward context. */
 int gut_optimize_after_bwd(gut_handle h, void* stream, int32_t num_active_features, const float* d_camera_position,
                            float* d_raw12, float* d_raw_m, float* d_raw_v, float* d_sh48, float* d_sh_m, float* d_sh_v,

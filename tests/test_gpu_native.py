@@ -758,7 +758,14 @@ def test_checkpoint_resume_beyond_the_decay_tables():
     sd = lazy.state_dict()                                     # ... and the checkpoint holds current ones
     assert sd["step"] == 1506 and not torch.equal(stale, sd["exp_avg_features"])
     assert torch.allclose(sd["exp_avg_sq_features"], eager.v48, rtol=2e-6, atol=0.0)
-    assert torch.allclose(sd["exp_avg_features"], eager.m48, rtol=1e-5, atol=1e-12)
+    _d = (sd["exp_avg_features"] - eager.m48).abs()
+    # Two GPU runs, not a run against a reference: the backward accumulates each Gaussian's gradient with float atomics in an order
+    # that differs from run to run, so an element of the first moment carries an ABSOLUTE noise of about 0.1 x 2^-24 x sum |terms| per
+    # step (a few 1e-10 for this scene's colour gradients) whatever its own size, and an element that happens to sit near zero cannot
+    # meet a purely relative bound (one such element in 960 k failed atol 1e-12 once in eight runs of the suite).  2e-9 is 2e-5 of the
+    # moments' typical magnitude (1e-4).
+    assert torch.allclose(sd["exp_avg_features"], eager.m48, rtol=1e-5, atol=2e-9), \
+        f"max abs diff {float(_d.max()):.3e} at |value| {float(eager.m48.flatten()[_d.argmax()].abs()):.3e}, {int((_d > 1e-5 * eager.m48.abs() + 1e-12).sum())} elements over"
     # resume into a fresh trainer
     resumed = make(True)
     resumed.model.raw.copy_(lazy.model.raw); resumed.model.features.copy_(lazy.model.features)
