@@ -639,32 +639,42 @@ __global__ __launch_bounds__(kBlock, 5) void k_project_on_tiles(ViewParams v, Re
 }
 
 // K2, second level: exclusive scan of the per-256-row-block sums (one uint4 of wave sums per block) by ONE workgroup — 23 k values at
-// 6 M Gaussians, one iteration — and the frame's intersection count.  block_prefix[b] = list entries of all Gaussians before
+// 6 M Gaussians, three iterations of 8192 through LDS — and the frame's intersection count.  block_prefix[b] = list entries of all Gaussians before
 // block b; *total = M.
 // host_out (pinned host memory, may be null): [0] = M, [2], [3] = walk_sums of the last frame that had a backward — what the host reads
 // once it has queued the rest of the frame; written from here instead of by two stream-ordered 4- and 8-byte copies (~12 us each).
 __global__ __launch_bounds__(1024) void k_scan_wave_sums(const uint4* __restrict__ wave_sums4, uint32_t nblocks,
                                                          uint32_t* __restrict__ block_prefix, uint32_t* __restrict__ total,
                                                          uint32_t* __restrict__ host_out, const uint32_t* __restrict__ walk_sums) {
+    constexpr uint32_t kPer = 8;                 // block sums per thread and iteration
+    constexpr uint32_t kChunk = 1024u * kPer;    // 8192 blocks = 2.1 M Gaussians per iteration
+    __shared__ uint32_t s_val[kChunk + kChunk / 32];   // (+1 word per 32: a thread's eight consecutive words spread over the banks)
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) s_carry = 0u;
     __syncthreads();
-    constexpr uint32_t kPer = 24;  // consecutive blocks per thread: 6.29 M Gaussians per iteration (one load latency, one scan)
-    for (uint32_t base = 0; base < nblocks; base += 1024u * kPer) {
-        uint32_t local[kPer];
-        uint32_t sum = 0;
+    auto slot = [](uint32_t e) { return e + (e >> 5); };
+    for (uint32_t base = 0; base < nblocks; base += kChunk) {
+        // coalesced 16-byte loads (consecutive lanes, consecutive blocks): the first version gave every lane 24 consecutive uint4 —
+        // 64 different cache lines per load instruction, 25 k line requests through one CU's L1, and took 28 us
 #pragma unroll
         for (uint32_t k = 0; k < kPer; ++k) {
-            const uint32_t b = base + tid * kPer + k;
+            const uint32_t e = k * 1024u + tid, b = base + e;
             uint32_t v = 0;
             if (b < nblocks) {
                 const uint4 w = wave_sums4[b];
                 v = w.x + w.y + w.z + w.w;
             }
+            s_val[slot(e)] = v;
+        }
+        __syncthreads();
+        uint32_t local[kPer];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {   // this thread's eight consecutive blocks
             local[k] = sum;
-            sum += v;
+            sum += s_val[slot(tid * kPer + k)];
         }
         uint32_t incl = sum;   // inclusive scan over the wave
 #pragma unroll
@@ -683,11 +693,13 @@ __global__ __launch_bounds__(1024) void k_scan_wave_sums(const uint4* __restrict
         }
         const uint32_t excl = s_carry + wave_excl + (incl - sum);
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; ++k) {
-            const uint32_t b = base + tid * kPer + k;
-            if (b < nblocks) block_prefix[b] = excl + local[k];
-        }
+        for (uint32_t k = 0; k < kPer; ++k) s_val[slot(tid * kPer + k)] = excl + local[k];
         __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {   // coalesced stores
+            const uint32_t e = k * 1024u + tid, b = base + e;
+            if (b < nblocks) block_prefix[b] = s_val[slot(e)];
+        }
         if (tid == 0) s_carry += iter_total;
         __syncthreads();
     }
