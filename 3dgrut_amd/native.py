@@ -585,7 +585,9 @@ class NativeTrainStep:
             need = self._lib.gut_photometric_workspace_bytes(H, W)
             if self._loss_ws is None or self._loss_ws.numel() * 4 < need:
                 self._loss_ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=rgba.device)
-                self._loss3 = torch.empty((3,), dtype=torch.float32, device=rgba.device)
+            # three fresh floats every step (the caching allocator, no kernel): the loss returned below is a VIEW of them — a
+            # `.clone()` of a buffer kept across steps was a 7 us copy kernel between the loss and the backward
+            self._loss3 = torch.empty((3,), dtype=torch.float32, device=rgba.device)
             rgba_grad = torch.empty_like(rgba)
             st = torch.cuda.current_stream(rgba.device).cuda_stream
             rc = self._lib.gut_photometric_loss(C.c_void_p(st), H, W, rgba.data_ptr(), gt.data_ptr(),
@@ -593,7 +595,7 @@ class NativeTrainStep:
                                                 self._loss_ws.data_ptr(), self._loss3.data_ptr(), rgba_grad.data_ptr())
             if rc:
                 raise RuntimeError(f"[3dgut] photometric_loss failed ({rc})")
-            loss = self._loss3[0].clone()
+            loss = self._loss3[0]
             pred_rgb = rgba[..., :3].unsqueeze(0)
             if m.background_color == "white":
                 pred_rgb = pred_rgb + (1.0 - rgba[..., 3:].unsqueeze(0))
