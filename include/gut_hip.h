@@ -282,7 +282,8 @@ int gut_debug_copy(gut_handle h, int32_t which, void* d_dst, size_t bytes);
  * bracketed by events.  0 = all of them; 2 = none (as with enable_kernel_timings = 0, switchable at run time: bench.py times its
  * steps this way and collects the per-kernel times in a second pass — the two dozen event records per train step cost 5 - 7 % of
  * a 2.4 ms step on MI355X); 1 = only the optimiser launches on the library's side stream (measured: SLOWER than either, the side
- * stream's second launch takes 1.7 instead of 1.1 ms when the caller's stream carries no events — kept for experiments).  Timers of
+ * stream's second launch loses its head start over the backward compositor to the timing event's barrier packet and takes 1.7
+ * instead of 1.1 ms — kept for experiments).  Timers of
  * boundaries that were not bracketed read -1. */
 #define GUT_OPT_KERNEL_TIMING_SET 5
 #define GUT_OPT_DEBUG_REPLACE_SCRATCH 100
