@@ -512,6 +512,30 @@ def test_rolling_shutter_iteration_count(iterations, kind):
     assert np.abs(rgba.cpu().numpy() - ref["rgba"]).max() <= 2e-4
 
 
+def test_host_count_follows_the_device_count_every_frame():
+    """The intersection count reaches the host through system-scope stores of the scan kernel into coherent pinned memory and an event
+    WITHOUT a system-scope fence (gut_api.cpp: kOrderingEvent, k_scan_wave_sums).  300 frames over four views with different counts (275 k - 447 k):
+    the host's count of every frame (stats: what sizes the binning buffers and detects an overflow) must be that frame's device
+    count, never the previous frame's."""
+    sc = scenes.scene_c1(60000, 12)
+    W, H = 160, 120
+    views = [make_view("pinhole", W, H, cams.look_at_c2w(eye, (0, 0, 0)), fx=f) for eye, f in
+             (((0.0, 0.0, -4.0), 150.0), ((0.3, 0.2, -1.2), 60.0), ((2.5, 0.1, -0.4), 220.0), ((0.0, 0.1, -9.0), 400.0))]
+    model = gut_model(sc, 3)
+    tr = gut.Tracer({"render": {}})
+    raster = tr.tracer_wrapper
+    batches = [to_batch(v, DEV) for v in views]
+    seen = set()
+    with torch.no_grad():
+        for k in range(300):
+            tr.render(model, batches[(k * 7 + k // 5) % len(batches)], train=False, frame_id=k)
+            m_host = raster.stats()["num_intersections"]
+            m_dev = int(raster.debug_buffer("tiles_count").view(torch.int32).sum().item())
+            assert m_host == m_dev, f"frame {k}: host {m_host}, device {m_dev}"
+            seen.add(m_host)
+    assert len(seen) == len(views) and max(seen) > 1.5 * min(seen)   # every view has its own count: a stale one would have shown
+
+
 def test_timings_surface():
     sc = scenes.scene_c1(500, 2)
     view = make_view("pinhole", 64, 64, cams.look_at_c2w((0, 0, -4), (0, 0, 0)), fx=64)
