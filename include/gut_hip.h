@@ -34,7 +34,10 @@ extern "C" {
  * 4: gut_trace_model_fields / gut_trace_bwd_model_fields, gut_position_gradient_statistics, gut_set_position_gradient_statistics,
  * gut_mcmc_perturb; 5: behaviour, not layout — GUT_OPT_SORTED_REFERENCE_BACKWARD defaults to 1, the reference's own form of the
  * sorted variant's backward; the UT sigma-point spread is rounded from double like the reference's build script does;
- * GutLazyMoments.d_overrun; gut_trace_raw_model_fields; GUT_OPT_FORWARD_TILE_ORDER). */
+ * GutLazyMoments.d_overrun; gut_trace_raw_model_fields; GUT_OPT_FORWARD_TILE_ORDER).  Added under 5 without a bump, nothing that was
+ * accepted changed meaning: gut_create takes every value of GutConfig the reference has a kernel for (kernel degree, SH storage degree,
+ * rolling-shutter iterations, hit counts), gut_optimize_after_bwd takes a NULL camera position, GUT_OPT_KERNEL_TIMING_SET, and the
+ * unsorted backward clamps alpha with the reference's literal 0.99 whatever particle_kernel_max_alpha is. */
 #define GUT_ABI_VERSION 5
 
 typedef struct gut_context* gut_handle;
