@@ -172,7 +172,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     float T = ray.valid ? 1.0f : -1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dsum = 0.f;
     uint32_t nhits = 0;
     bool have_lo = false;           // kLazy: the last list entry ordered so far (block-uniform)
-    uint32_t lo_d = 0, lo_p = 0, batch_n = 0, batch_used = 0;
+    unsigned long long lo = 0;
+    uint32_t batch_n = 0, batch_used = 0;
 
     uint32_t base = 0;  // list entries staged so far (kept after the loop: the ordered prefix handed to the backward)
     // The walk, instantiated twice on the block-uniform `centred` (every camera of the reference has centred rays): the centred form
@@ -192,19 +193,20 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
             if (kLazy) {
                 if (batch_used == batch_n) {  // block-uniform: order the next kLazyBatch entries of the tile
                     batch_n = min(kLazyBatch, total - base);
-                    lazy_select(s_lazy, tile_keys + range.x, total, batch_n, have_lo, lo_d, lo_p, tid);
+                    // (the staging area is free here: every wave has left the previous chunk at the barrier above)
+                    static_assert(sizeof(stage) >= kLazyCache * sizeof(uint32_t), "depth cache aliases the staging area");
+                    lazy_select(s_lazy, reinterpret_cast<uint32_t*>(stage), tile_keys + range.x, total, batch_n, have_lo, lo, tid);
 #ifdef GUT_CLOCK_STAMPS
                     k6_tB = __builtin_amdgcn_s_memtime();
                     GUT_K6_ADD(1, k6_tA, k6_tB);
 #endif
                     have_lo = true;
-                    lo_d = s_lazy.sel_depth[batch_n - 1];
-                    lo_p = s_lazy.sel_pos[batch_n - 1];
+                    lo = s_lazy.sel[batch_n - 1];
                     batch_used = 0;
                 }
                 const uint32_t take = min((uint32_t)kBlock, batch_n - batch_used);
                 if (tid < take) {
-                    id = sorted_ids[range.x + s_lazy.sel_pos[batch_used + tid]];
+                    id = sorted_ids[range.x + (uint32_t)s_lazy.sel[batch_used + tid]];
                     ordered_ids[k] = id;
                 }
                 batch_used += take;

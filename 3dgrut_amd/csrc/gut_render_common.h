@@ -257,43 +257,76 @@ __device__ __forceinline__ uint32_t strip_mask(const StripPlanes& sp, const View
 // selects the next <= 256 entries in (depth bits, list position) order — list position == particle-id order, i.e. exactly
 // the order the full stable sort on (tile | depth) produces — writes their ids to the ordered-id list (the backward and
 // the tests read that) and stages them.  Selection = 4 x 8-bit radix select on the depth bits among the entries behind the
-// last one taken, one ordered gather pass, one 256-element bitonic sort in LDS.
+// last one taken, one ordered gather pass, one 512-element bitonic sort in LDS.
 constexpr uint32_t kLazyBatch = 512;  // entries ordered per selection: two 256-entry chunks (power of two for the bitonic sort)
 
 struct LazyOrder {
     uint32_t hist[256];
-    uint32_t sel_depth[kLazyBatch];
-    uint32_t sel_pos[kLazyBatch];
+    unsigned long long sel[kLazyBatch];  // (depth bits << 32) | list position: one 64-bit compare orders two entries
     uint32_t wave_cnt[2][4][4];  // [less | equal][unrolled position][wave]
     uint32_t bin, need;
 };
 
 // keys: the tile's slice of the tile-grouped (tile << 32 | depth bits) keys; total = its length; want = min(kLazyBatch,
-// entries not yet taken); (have_lo, lo_d, lo_p) = the last entry taken so far.  Called by all 256 threads (contains
-// barriers).  On return sel_pos[t] / sel_depth[t], t < want, hold the next `want` entries in final order.
-// Every pass walks the list four 256-entry rows at a time with the four loads issued back to back.  (Not inlined: inlined,
-// its register needs made the compiler spill the compositing loop's state, 2.4x slower; a variant that kept the first 4 .. 16
-// rows of depths in registers across the passes was measured slower as well, for the same reason.)
+// entries not yet taken); (have_lo, lo) = the last entry taken so far, in sel[]'s form.  Called by all 256 threads (contains
+// barriers).  On return sel[t], t < want, hold the next `want` entries in final order.
+// The tile's depths (the first kLazyCache of them) are copied ONCE per selection into LDS the compositing loop is not using at
+// that moment (kcache = its staging area: the previous chunk has been walked, the next is not staged yet) and the four digit
+// passes and the gather read them from there: one round of L2 / HBM latency per selection instead of five.  Only lists longer
+// than the cache stream their remainder from memory in every pass, four 256-entry rows at a time with the four loads issued
+// back to back.  Histogram increments are aggregated per wave on the digit of the wave's first counting lane (the high digits
+// of a tile's depths are nearly all equal: one LDS atomic instead of 64 serialised ones).
+// (Not inlined: inlined, its register needs made the compiler spill the compositing loop's state, 2.4x slower; keeping 8 or 12
+// rows of depths in REGISTERS across the passes instead of in LDS does the same to the caller even when not inlined — the
+// values the loop keeps live across the call no longer fit beside the callee's: 9 scratch accesses inside the per-entry loop.)
+constexpr uint32_t kLazyCache = 4096;  // depth words: 16 KB = sizeof(PackEntry) * kBlock
 
-__device__ __noinline__ void lazy_select(LazyOrder& S, const uint2* __restrict__ keys, uint32_t total, uint32_t want, bool have_lo,
-                                         uint32_t lo_d, uint32_t lo_p, uint32_t tid) {
+__device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kcache, const uint2* __restrict__ keys, uint32_t total,
+                                         uint32_t want, bool have_lo, unsigned long long lo, uint32_t tid) {
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    auto behind_lo = [&](uint32_t d, uint32_t p) { return !have_lo || d > lo_d || (d == lo_d && p > lo_p); };
+    auto behind_lo = [&](uint32_t d, uint32_t p) { return !have_lo || (((unsigned long long)d << 32) | p) > lo; };
+    const uint32_t cached = min(total, kLazyCache);
+    for (uint32_t base = 0; base < cached; base += 8 * kBlock) {
+        uint32_t d[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) d[u] = (base + u * kBlock + tid) < cached ? keys[base + u * kBlock + tid].x : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u)
+            if ((base + u * kBlock + tid) < cached) kcache[base + u * kBlock + tid] = d[u];
+    }
+    // four consecutive 256-entry rows of depths starting at the block-uniform `base` (a multiple of 4 * kBlock, so a group is
+    // cached as a whole or not at all)
+    auto fetch4 = [&](uint32_t base, uint32_t (&d)[4]) {
+        if (base < kLazyCache) {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) d[u] = (base + u * kBlock + tid) < total ? kcache[base + u * kBlock + tid] : 0u;
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) d[u] = (base + u * kBlock + tid) < total ? keys[base + u * kBlock + tid].x : 0u;
+        }
+    };
     // 1. depth of the want-th smallest remaining entry, digit by digit
     uint32_t prefix = 0, need = want;
     for (int shift = 24; shift >= 0; shift -= 8) {
         S.hist[tid] = 0u;
-        __syncthreads();
+        __syncthreads();  // (first pass: the cache is complete behind this barrier too)
         const uint32_t hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (uint32_t p0 = tid; p0 < total; p0 += 4 * kBlock) {
+        for (uint32_t base = 0; base < total; base += 4 * kBlock) {
             uint32_t d[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; ++u) d[u] = (p0 + u * kBlock) < total ? keys[p0 + u * kBlock].x : 0u;
+            fetch4(base, d);
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u) {
-                const uint32_t p = p0 + u * kBlock;
-                if (p < total && behind_lo(d[u], p) && ((d[u] & hi_mask) == (prefix & hi_mask)))
-                    atomicAdd(&S.hist[(d[u] >> shift) & 255u], 1u);
+                const uint32_t p = base + u * kBlock + tid;
+                const bool ok = p < total && behind_lo(d[u], p) && ((d[u] & hi_mask) == (prefix & hi_mask));
+                const unsigned long long b_ok = __ballot(ok);
+                if (b_ok == 0ull) continue;  // wave-uniform
+                const uint32_t digit = (d[u] >> shift) & 255u;
+                const uint32_t first = (uint32_t)__ffsll((long long)b_ok) - 1u;
+                const uint32_t lead = (uint32_t)__shfl((int)digit, (int)first);
+                const bool same = ok && digit == lead;
+                const unsigned long long b_same = __ballot(same);
+                if (lane == first) atomicAdd(&S.hist[lead], (uint32_t)__popcll(b_same));
+                if (ok && !same) atomicAdd(&S.hist[digit], 1u);
             }
         }
         __syncthreads();
@@ -327,8 +360,7 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, const uint2* __restrict__
         uint32_t d[4];
         unsigned long long b_lt[4], b_eq[4];
         bool lt[4], eq[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) d[u] = (base + u * kBlock + tid) < total ? keys[base + u * kBlock + tid].x : 0u;
+        fetch4(base, d);
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t p = base + u * kBlock + tid;
@@ -357,26 +389,26 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, const uint2* __restrict__
             my_lt += (uint32_t)__popcll(b_lt[u] & below);
             my_eq += (uint32_t)__popcll(b_eq[u] & below);
             const uint32_t p = base + u * kBlock + tid;
-            if (lt[u]) { S.sel_depth[my_lt] = d[u]; S.sel_pos[my_lt] = p; }
-            if (eq[u] && my_eq < need) { S.sel_depth[n_less + my_eq] = d[u]; S.sel_pos[n_less + my_eq] = p; }
+            const unsigned long long key = ((unsigned long long)d[u] << 32) | p;
+            if (lt[u]) S.sel[my_lt] = key;
+            if (eq[u] && my_eq < need) S.sel[n_less + my_eq] = key;
         }
         got_lt = run_lt;
         got_eq = run_eq;
         __syncthreads();
     }
     for (uint32_t t = tid; t < kLazyBatch; t += kBlock)
-        if (t >= want) { S.sel_depth[t] = 0xFFFFFFFFu; S.sel_pos[t] = 0xFFFFFFFFu; }
+        if (t >= want) S.sel[t] = ~0ull;
     __syncthreads();
     // 3. bitonic sort of the kLazyBatch slots by (depth, position); every thread owns one compare-exchange per stage
     for (uint32_t k = 2; k <= kLazyBatch; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < kLazyBatch / 2; t += kBlock) {
                 const uint32_t e = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), o = e | j;
-                const uint32_t d0 = S.sel_depth[e], p0 = S.sel_pos[e], d1 = S.sel_depth[o], p1 = S.sel_pos[o];
-                const bool gt = d0 > d1 || (d0 == d1 && p0 > p1);
-                if (gt == ((e & k) == 0u)) {
-                    S.sel_depth[e] = d1; S.sel_pos[e] = p1;
-                    S.sel_depth[o] = d0; S.sel_pos[o] = p0;
+                const unsigned long long a = S.sel[e], b = S.sel[o];
+                if ((a > b) == ((e & k) == 0u)) {
+                    S.sel[e] = b;
+                    S.sel[o] = a;
                 }
             }
             __syncthreads();
