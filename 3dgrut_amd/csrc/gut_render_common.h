@@ -256,15 +256,15 @@ __device__ __forceinline__ uint32_t strip_mask(const StripPlanes& sp, const View
 // entries stay in particle-id order) and the forward compositor orders each tile on demand: before it stages a chunk it
 // selects the next <= 256 entries in (depth bits, list position) order — list position == particle-id order, i.e. exactly
 // the order the full stable sort on (tile | depth) produces — writes their ids to the ordered-id list (the backward and
-// the tests read that) and stages them.  Selection = 4 x 8-bit radix select on the depth bits among the entries behind the
-// last one taken, one ordered gather pass, one 512-element bitonic sort in LDS.
+// the tests read that) and stages them.  Selection = up to 4 x 8-bit radix select on the depth bits among the entries behind
+// the last one taken, one ordered gather pass, one 512-element bitonic sort in LDS.
 constexpr uint32_t kLazyBatch = 512;  // entries ordered per selection: two 256-entry chunks (power of two for the bitonic sort)
 
 struct LazyOrder {
     uint32_t hist[256];
     unsigned long long sel[kLazyBatch];  // (depth bits << 32) | list position: one 64-bit compare orders two entries
     uint32_t wave_cnt[2][4][4];  // [less | equal][unrolled position][wave]
-    uint32_t bin, need;
+    uint32_t bin, need, bin_count;
 };
 
 // keys: the tile's slice of the tile-grouped (tile << 32 | depth bits) keys; total = its length; want = min(kLazyBatch,
@@ -306,7 +306,11 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
         }
     };
     // 1. depth of the want-th smallest remaining entry, digit by digit
-    uint32_t prefix = 0, need = want;
+    // The passes stop as soon as the bin that holds the want-th entry has at most 64 members (normally after the second: 16
+    // depth bits leave about a dozen): a single wave then ranks that bin's members exactly (step 2b) instead of two more
+    // passes over the whole list.
+    uint32_t prefix = 0, need = want, cmask = 0xFFFFFFFFu;  // cmask: the depth bits the passes have decided
+    bool short_bin = false;
     for (int shift = 24; shift >= 0; shift -= 8) {
         S.hist[tid] = 0u;
         __syncthreads();  // (first pass: the cache is complete behind this barrier too)
@@ -345,18 +349,29 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
                 if (c + h0 < need) { c += h0; ++b; if (c + h1 < need) { c += h1; ++b; if (c + h2 < need) { c += h2; ++b; } } }
                 S.bin = b;
                 S.need = need - c;
+                S.bin_count = S.hist[b];
             }
         }
         __syncthreads();
         prefix |= S.bin << shift;
         need = S.need;
+        if (shift > 0 && S.bin_count <= 64u) {  // block-uniform
+            short_bin = true;
+            cmask = 0xFFFFFFFFu << shift;
+            break;
+        }
     }
-    const uint32_t dstar = prefix;       // its depth bits; `need` entries with exactly this depth are taken, in list order
-    const uint32_t n_less = want - need;  // entries with a smaller depth: all taken
+    const uint32_t dstar = prefix;        // the decided depth bits of the want-th entry: `need` of the entries that share them are taken
+    const uint32_t n_less = want - need;  // entries below them: all taken
+    // the bin's members: straight into their slots in list order when the bin is one exact depth (only `need` of them fit), else
+    // into a side list (the histogram's storage, free now) that step 2b ranks
+    const uint32_t bin_count = S.bin_count;
+    unsigned long long* const eq_dst = short_bin ? reinterpret_cast<unsigned long long*>(S.hist) : S.sel + n_less;
+    const uint32_t eq_cap = short_bin ? bin_count : need;
     // 2. ordered gather (list order = row, then wave, then lane)
     uint32_t got_lt = 0, got_eq = 0;
     for (uint32_t base = 0; base < total; base += 4 * kBlock) {
-        if (got_lt == n_less && got_eq >= need) break;  // block-uniform
+        if (got_lt == n_less && got_eq >= eq_cap) break;  // block-uniform
         uint32_t d[4];
         unsigned long long b_lt[4], b_eq[4];
         bool lt[4], eq[4];
@@ -365,8 +380,8 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
         for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t p = base + u * kBlock + tid;
             const bool cand = (p < total) && behind_lo(d[u], p);
-            lt[u] = cand && d[u] < dstar;
-            eq[u] = cand && d[u] == dstar;
+            lt[u] = cand && (d[u] & cmask) < dstar;
+            eq[u] = cand && (d[u] & cmask) == dstar;
             b_lt[u] = __ballot(lt[u]);
             b_eq[u] = __ballot(eq[u]);
             if (lane == 0) {
@@ -391,11 +406,18 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
             const uint32_t p = base + u * kBlock + tid;
             const unsigned long long key = ((unsigned long long)d[u] << 32) | p;
             if (lt[u]) S.sel[my_lt] = key;
-            if (eq[u] && my_eq < need) S.sel[n_less + my_eq] = key;
+            if (eq[u] && my_eq < eq_cap) eq_dst[my_eq] = key;
         }
         got_lt = run_lt;
         got_eq = run_eq;
         __syncthreads();
+    }
+    // 2b. the `need` smallest of a short bin's members, each to the slot of its rank among them (keys are distinct)
+    if (short_bin && wave == 0) {
+        const unsigned long long key = lane < bin_count ? eq_dst[lane] : ~0ull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < bin_count; ++j) rank += eq_dst[j] < key ? 1u : 0u;  // (one broadcast LDS read per member)
+        if (lane < bin_count && rank < need) S.sel[n_less + rank] = key;
     }
     for (uint32_t t = tid; t < kLazyBatch; t += kBlock)
         if (t >= want) S.sel[t] = ~0ull;
