@@ -265,6 +265,7 @@ struct LazyOrder {
     unsigned long long sel[kLazyBatch];  // (depth bits << 32) | list position: one 64-bit compare orders two entries
     uint32_t wave_cnt[2][4][4];  // [less | equal][unrolled position][wave]
     uint32_t bin, need, bin_count;
+    uint32_t cnt_lt, cnt_eq;  // slots handed out by the unordered gather
 };
 
 // keys: the tile's slice of the tile-grouped (tile << 32 | depth bits) keys; total = its length; want = min(kLazyBatch,
@@ -285,6 +286,11 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
                                          uint32_t want, bool have_lo, unsigned long long lo, uint32_t tid) {
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     auto behind_lo = [&](uint32_t d, uint32_t p) { return !have_lo || (((unsigned long long)d << 32) | p) > lo; };
+    // (the ballot of a condition as it stands in the condition register: __ballot() materialises an int per lane first)
+    auto ballot = [](bool b) -> unsigned long long { return __builtin_amdgcn_ballot_w64(b); };
+    auto lanes_below = [](unsigned long long b) -> uint32_t {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    };
     const uint32_t cached = min(total, kLazyCache);
     for (uint32_t base = 0; base < cached; base += 8 * kBlock) {
         uint32_t d[8];
@@ -322,13 +328,13 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
             for (uint32_t u = 0; u < 4; ++u) {
                 const uint32_t p = base + u * kBlock + tid;
                 const bool ok = p < total && behind_lo(d[u], p) && ((d[u] & hi_mask) == (prefix & hi_mask));
-                const unsigned long long b_ok = __ballot(ok);
+                const unsigned long long b_ok = ballot(ok);
                 if (b_ok == 0ull) continue;  // wave-uniform
                 const uint32_t digit = (d[u] >> shift) & 255u;
-                const uint32_t first = (uint32_t)__ffsll((long long)b_ok) - 1u;
-                const uint32_t lead = (uint32_t)__shfl((int)digit, (int)first);
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)b_ok) - 1);
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)digit, (int)first);
                 const bool same = ok && digit == lead;
-                const unsigned long long b_same = __ballot(same);
+                const unsigned long long b_same = ballot(same);
                 if (lane == first) atomicAdd(&S.hist[lead], (uint32_t)__popcll(b_same));
                 if (ok && !same) atomicAdd(&S.hist[digit], 1u);
             }
@@ -350,6 +356,8 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
                 S.bin = b;
                 S.need = need - c;
                 S.bin_count = S.hist[b];
+                S.cnt_lt = 0u;
+                S.cnt_eq = 0u;
             }
         }
         __syncthreads();
@@ -368,8 +376,37 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
     const uint32_t bin_count = S.bin_count;
     unsigned long long* const eq_dst = short_bin ? reinterpret_cast<unsigned long long*>(S.hist) : S.sel + n_less;
     const uint32_t eq_cap = short_bin ? bin_count : need;
-    // 2. ordered gather (list order = row, then wave, then lane)
+    // 2. gather.  Short bin: in any order — the sort orders the slots and step 2b ranks the bin's members —, a wave takes the
+    // slots of a row's entries with one returning LDS atomic.  Else ordered (list order = row, then wave, then lane): of the
+    // entries at the exact depth the first `need` of the list are the ones to take.
     uint32_t got_lt = 0, got_eq = 0;
+    if (short_bin) {
+        for (uint32_t base = 0; base < total; base += 4 * kBlock) {
+            uint32_t d[4];
+            fetch4(base, d);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t p = base + u * kBlock + tid;
+                const bool cand = (p < total) && behind_lo(d[u], p);
+                const bool lt = cand && (d[u] & cmask) < dstar, eq = cand && (d[u] & cmask) == dstar;
+                const unsigned long long key = ((unsigned long long)d[u] << 32) | p;
+                const unsigned long long b_lt = ballot(lt), b_eq = ballot(eq);
+                if (b_lt != 0ull) {  // wave-uniform
+                    uint32_t off = 0;
+                    if (lane == 0) off = atomicAdd(&S.cnt_lt, (uint32_t)__popcll(b_lt));
+                    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+                    if (lt) S.sel[off + lanes_below(b_lt)] = key;
+                }
+                if (b_eq != 0ull) {
+                    uint32_t off = 0;
+                    if (lane == 0) off = atomicAdd(&S.cnt_eq, (uint32_t)__popcll(b_eq));
+                    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+                    if (eq) eq_dst[off + lanes_below(b_eq)] = key;
+                }
+            }
+        }
+        __syncthreads();
+    } else
     for (uint32_t base = 0; base < total; base += 4 * kBlock) {
         if (got_lt == n_less && got_eq >= eq_cap) break;  // block-uniform
         uint32_t d[4];
@@ -382,15 +419,14 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
             const bool cand = (p < total) && behind_lo(d[u], p);
             lt[u] = cand && (d[u] & cmask) < dstar;
             eq[u] = cand && (d[u] & cmask) == dstar;
-            b_lt[u] = __ballot(lt[u]);
-            b_eq[u] = __ballot(eq[u]);
+            b_lt[u] = ballot(lt[u]);
+            b_eq[u] = ballot(eq[u]);
             if (lane == 0) {
                 S.wave_cnt[0][u][wave] = (uint32_t)__popcll(b_lt[u]);
                 S.wave_cnt[1][u][wave] = (uint32_t)__popcll(b_eq[u]);
             }
         }
         __syncthreads();
-        const unsigned long long below = (1ull << lane) - 1ull;
         uint32_t run_lt = got_lt, run_eq = got_eq;
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
@@ -401,8 +437,8 @@ __device__ __noinline__ void lazy_select(LazyOrder& S, uint32_t* __restrict__ kc
                 run_lt += S.wave_cnt[0][u][w];
                 run_eq += S.wave_cnt[1][u][w];
             }
-            my_lt += (uint32_t)__popcll(b_lt[u] & below);
-            my_eq += (uint32_t)__popcll(b_eq[u] & below);
+            my_lt += lanes_below(b_lt[u]);
+            my_eq += lanes_below(b_eq[u]);
             const uint32_t p = base + u * kBlock + tid;
             const unsigned long long key = ((unsigned long long)d[u] << 32) | p;
             if (lt[u]) S.sel[my_lt] = key;
