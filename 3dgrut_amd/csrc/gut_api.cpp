@@ -1201,11 +1201,15 @@ int gut_optimize_rows_without_gradient(gut_handle h, void* stream_, float* d_raw
     static int split_percent = -1;
     if (split_percent < 0) {
         const char* e = getenv("GUT_EARLY_SPLIT");  // tuning experiments only
-        split_percent = e ? atoi(e) : 25;
-        if (split_percent < 0 || split_percent > 100) split_percent = 25;
+        split_percent = e ? atoi(e) : -1;
+        if (split_percent > 100) split_percent = -1;
     }
     const uint32_t nblocks = (h->n + gut::kBlock - 1) / gut::kBlock;
-    const uint32_t first = (uint32_t)((uint64_t)nblocks * (uint32_t)split_percent / 100u);
+    // share of the row blocks whose tile-less waves go to the first launch, beside the forward compositor: 60 % in the
+    // 32-register form that launch has with lazy moments (about what it streams while K6 and the loss kernels run on the bench
+    // frame: 50 / 75 / 100 % measured 2.30 / 2.29 / 2.40 ms per step), 25 % in the wide form (which takes K6's fifth wave)
+    const uint32_t percent = split_percent >= 0 ? (uint32_t)split_percent : ((lazy && lazy->d_wave_step) ? 60u : 25u);
+    const uint32_t first = (uint32_t)((uint64_t)nblocks * percent / 100u);
     gut::launch_adam_rows_without_gradient(h->side_stream, h->n, h->tiles_count.as<uint32_t>(), d_raw12, d_raw_m, d_raw_v, d_sh48,
                                            d_sh_m, d_sh_v, lr12, lr48, beta1, beta2, eps, step, d_act12_out, 0, first, nullptr, first, 0,
                                            false, gut_make_lazy(lazy, step));

@@ -14,12 +14,24 @@ namespace gut {
 // raw row: pos3 | density logit | quat4 (unnormalised) | log-scale3 | unused
 // act row: pos3 | sigmoid       | quat4 / |quat|       | exp3       | |quat|   (the norm rides in the pad column so
 //          that the backward epilogue can chain through the normalisation without re-reading the raw row)
-__device__ __forceinline__ void activate_row(const float4& a, const float4& q, const float4& s, float4* __restrict__ act_row) {
+// (the three float4 of the row depend on one raw float4 each, plus the quaternion's norm for the last)
+__device__ __forceinline__ float4 activate_position_density(const float4& a) {
+    return make_float4(a.x, a.y, a.z, 1.0f / (1.0f + expf(-a.w)));
+}
+__device__ __forceinline__ float4 activate_quaternion(const float4& q, float* clamped_norm) {
     const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
     const float inv = 1.0f / fmaxf(nrm, 1e-12f);  // torch.nn.functional.normalize eps
-    act_row[0] = make_float4(a.x, a.y, a.z, 1.0f / (1.0f + expf(-a.w)));
-    act_row[1] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-    act_row[2] = make_float4(expf(s.x), expf(s.y), expf(s.z), fmaxf(nrm, 1e-12f));
+    *clamped_norm = fmaxf(nrm, 1e-12f);
+    return make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+}
+__device__ __forceinline__ float4 activate_scale(const float4& s, float clamped_norm) {
+    return make_float4(expf(s.x), expf(s.y), expf(s.z), clamped_norm);
+}
+__device__ __forceinline__ void activate_row(const float4& a, const float4& q, const float4& s, float4* __restrict__ act_row) {
+    float nrm;
+    act_row[0] = activate_position_density(a);
+    act_row[1] = activate_quaternion(q, &nrm);
+    act_row[2] = activate_scale(s, nrm);
 }
 
 __global__ __launch_bounds__(kBlock) void k_activate_pack(uint32_t n, const float4* __restrict__ raw, float4* __restrict__ act) {
@@ -664,6 +676,70 @@ __global__ __launch_bounds__(kBlock, 4) void k_adam_rows_without_gradient(AdamPa
     }
 }
 
+// The same pass (lazy moments) within 32 registers per lane, for the launch that runs beside the FORWARD compositor: K6 holds five
+// 96-register waves per SIMD (480 of 512), so a co-resident wave of this size costs it none of them, where the 72-register form
+// above takes the fifth.  One (p, m, v) group in flight per lane, wave-uniform bases with 32-bit lane offsets: latency-bound,
+// about a third of the streaming rate — still more rows than the wide form could be given under K6.  Same arithmetic, bit for
+// bit (adam4_lazy, the pieces of activate_row).  (amdgpu_num_vgpr counts each half of the unified file: 16 = 32 registers.)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_vgpr(16))) void k_adam_rows_without_gradient_narrow(
+    AdamParams a12, AdamParams a48, uint32_t n, const uint32_t* __restrict__ tiles_count, float4* __restrict__ p12,
+    float4* __restrict__ m12, float4* __restrict__ v12, float4* __restrict__ p48, float4* __restrict__ m48,
+    float4* __restrict__ v48, float4* __restrict__ act12, uint32_t block_begin, uint32_t block_end, EarlyOwnership own,
+    uint32_t second_launch, LazyMoments lazy) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __builtin_amdgcn_s_setprio(1);
+    __shared__ float4 s_lr48[12];
+    if (threadIdx.x < 12) s_lr48[threadIdx.x] = make_float4(a48.lr[4 * threadIdx.x], a48.lr[4 * threadIdx.x + 1], a48.lr[4 * threadIdx.x + 2],
+                                                           a48.lr[4 * threadIdx.x + 3]);
+    __syncthreads();
+    for (uint32_t blk = block_begin + blockIdx.x; blk < block_end; blk += gridDim.x) {
+        const uint32_t wave_first = blk * kBlock + wave * 64u;  // wave-uniform
+        if (wave_first >= n) continue;
+        const uint32_t rows_here = min(64u, n - wave_first);
+        const bool has_tiles = tiles_count ? (__ballot(lane < rows_here && tiles_count[wave_first + lane] != 0) != 0ull) : true;
+        if (!side_stream_owns_wave(own, has_tiles, wave_first >> 6, blk, second_launch != 0u)) continue;
+        const float2 dk = missed_decay(lazy, wave_first >> 6);
+        const LazyAdam l12 = make_lazy_adam(a12, dk), l48 = make_lazy_adam(a48, dk);
+        if (lane < rows_here) {
+            float4* rp = p12 + 3 * (size_t)wave_first;
+            const float4* rm = m12 + 3 * (size_t)wave_first;
+            const float4* rv = v12 + 3 * (size_t)wave_first;
+            float4* ra = act12 + 3 * (size_t)wave_first;
+            uint32_t o = 3u * lane;
+            asm volatile("" : "+v"(o));  // (keeps the six per-lane 64-bit addresses from being hoisted out of the loop and spilled)
+            float4 x = rp[o];
+            adam4_lazy(l12, make_float4(a12.lr[0], a12.lr[1], a12.lr[2], a12.lr[3]), x, rm[o], rv[o]);
+            rp[o] = x;
+            if (act12) ra[o] = activate_position_density(x);
+            __builtin_amdgcn_sched_barrier(0);
+            x = rp[o + 1];
+            adam4_lazy(l12, make_float4(a12.lr[4], a12.lr[5], a12.lr[6], a12.lr[7]), x, rm[o + 1], rv[o + 1]);
+            rp[o + 1] = x;
+            float nrm = 0.0f;
+            if (act12) ra[o + 1] = activate_quaternion(x, &nrm);
+            __builtin_amdgcn_sched_barrier(0);
+            x = rp[o + 2];
+            adam4_lazy(l12, make_float4(a12.lr[8], a12.lr[9], a12.lr[10], a12.lr[11]), x, rm[o + 2], rv[o + 2]);
+            rp[o + 2] = x;
+            if (act12) ra[o + 2] = activate_scale(x, nrm);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float4* bp = p48 + (size_t)wave_first * 12;
+        const float4* bm = m48 + (size_t)wave_first * 12;
+        const float4* bv = v48 + (size_t)wave_first * 12;
+        uint32_t q0 = lane;
+        asm volatile("" : "+v"(q0));
+#pragma unroll 1
+        for (uint32_t q = q0; q < rows_here * 12u; q += 64u) {
+            const uint32_t col4 = q % 12u;
+            float4 pp = bp[q];
+            adam4_lazy(l48, s_lr48[col4], pp, bm[q], bv[q]);
+            bp[q] = pp;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Sparse gradient exchange of the data-parallel trainer.  A view gives a gradient only to the Gaussians its rays hit, a
 // small share of the scene, so what crosses xGMI per view is a list of 64-byte RECORDS
@@ -826,7 +902,16 @@ void launch_adam_rows_without_gradient(hipStream_t s, uint32_t n, const uint32_t
     }
     const uint32_t cap = (uint32_t)(second_launch ? wgs_per_cu2 : wgs_per_cu) * (uint32_t)num_cus;
     const uint32_t grid = nblocks < cap ? nblocks : cap;
-    auto kern = lazy.wave_step ? k_adam_rows_without_gradient<true> : k_adam_rows_without_gradient<false>;
+    // the first launch (beside K6) in its 32-register form wherever that form exists (lazy moments): measured on the bench frame,
+    // interleaved runs on one box, K6 0.476 -> 0.445 ms beside it (it keeps its fifth wave) and, with 60 % instead of 25 % of the
+    // row blocks given to the first launch, the second launch 1.05 -> 0.87 ms and the step's tail 0.27 -> 0.23 ms
+    static int narrow_first = -1;
+    if (narrow_first < 0) {
+        const char* e = getenv("GUT_EARLY_NARROW");  // tuning experiments only
+        narrow_first = e ? atoi(e) : 1;
+    }
+    auto kern = lazy.wave_step ? ((narrow_first && !second_launch) ? k_adam_rows_without_gradient_narrow : k_adam_rows_without_gradient<true>)
+                               : k_adam_rows_without_gradient<false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, a12, a48, n, tiles_count,
                        reinterpret_cast<float4*>(raw12), reinterpret_cast<float4*>(raw_m), reinterpret_cast<float4*>(raw_v),
                        reinterpret_cast<float4*>(sh48), reinterpret_cast<float4*>(sh_m), reinterpret_cast<float4*>(sh_v),

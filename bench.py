@@ -13,7 +13,9 @@ as a seeded synthetic stand-in (no datasets/checkpoints in the environment): sce
 Weak scaling: every rank renders its own view of the replicated scene each step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
-  "roofline":     dominant kernel's algorithmic bytes / its mean hipEvent duration over the timed region,
+  "roofline":     dominant HBM-bound kernel's algorithmic bytes / its mean hipEvent duration over the timed region,
+  "roofline_valu": the same for the step's longest launch when that is one of the two compositors, which are bound by
+                   vector-instruction issue (wave64 instructions per second against the chip's issue peak),
   "cpu_baseline": pure-PyTorch per-ray composite (oracle/per_ray_torch.py) on a bounded ray sample,
 plus "render_ms_per_frame" (forward-only, event time around the whole forward incl. sort + count readback,
 the reference's `forward_render` definition) and the scene statistics N,V,M,T,P,E_f,E_b.
@@ -51,6 +53,7 @@ WORKLOADS = {
     "garden_like_5M_1297x840": ("scene_outdoor_like", dict(n=5_000_000, seed=4), 1297, 840, 1090.0, 4.2, 15.0, 5.0),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_GINSTR_S = 1024 * 2.4 / 2.0   # wave64 VALU instructions per ns, chip-wide: one per SIMD every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 VALU_ISSUE_NS = 1.16   # one wave64 VALU instruction per SIMD every 1.16 ns with >= 2 waves resident (tools/pk_rate.hip, measured)
 
 
@@ -593,7 +596,12 @@ def main():
         # dominant kernel = the longest single launch of the step ("optimizer_early" is the span of the side stream's two launches,
         # idle gap included, and is reported under per_kernel only; "optimizer_early_2" is its second launch, timed with events
         # on the side stream it runs on)
-        dom = max((k for k in ktimes if ktimes[k] > 0 and k != "optimizer_early"), key=lambda k: ktimes[k])
+        longest = max((k for k in ktimes if ktimes[k] > 0 and k != "optimizer_early"), key=lambda k: ktimes[k])
+        # The two compositors are bound by vector-instruction issue, not by bytes or matrix flops: when one of
+        # them is the step's longest launch it gets its own block (`roofline_valu`, below) and `roofline` — whose bound is "hbm" or
+        # "mfma" by contract — describes the longest launch of the HBM-bound kernels, which is also the one that moves most bytes.
+        VALU_BOUND = ("render", "render_bwd")
+        dom = max((k for k in ktimes if ktimes[k] > 0 and k != "optimizer_early" and k not in VALU_BOUND), key=lambda k: ktimes[k])
         # achievable HBM bandwidth of THIS box, for context next to the 8 TB/s spec: device-to-device copy of 2 GB
         a = torch.empty(1 << 29, dtype=torch.float32, device=dev); b = torch.empty_like(a)
         b.copy_(a)
@@ -628,6 +636,21 @@ def main():
                                 "activation row written) UNDER the VALU-bound backward compositor and then beside the pass over the walked "
                                 "waves; it shares the chip by design and is no longer on the step's critical path; alone it runs at the "
                                 "box's device-copy rate (profiles/: optimizer_early_2, PMC pass)")
+        roofline_valu = None
+        if longest in VALU_BOUND:
+            roofline["longest_launch_of_the_step"] = longest + " (VALU-bound: see roofline_valu)"
+            c = pk(longest)
+            if "SQ_INSTS_VALU" in c:
+                # wave64 vector instructions per launch (SQ_INSTS_VALU of the tracked PMC pass, same workload) / this run's mean
+                # launch duration, against one instruction per SIMD every 2 cycles at 2.4 GHz on 1024 SIMDs (MI355X_MICROARCH.md)
+                rate = c["SQ_INSTS_VALU"] / (ktimes[longest] * 1e-3) / 1e9
+                roofline_valu = {"kernel": longest, "bound": "valu issue", "achieved": rate, "peak": VALU_PEAK_GINSTR_S,
+                                 "unit": "G wave64-instructions/s", "frac": rate / VALU_PEAK_GINSTR_S,
+                                 "frac_of_measured_issue_rate": c["SQ_INSTS_VALU"] * VALU_ISSUE_NS * 1e-9 / (1024 * ktimes[longest] * 1e-3),
+                                 "wave_instructions_per_launch": c["SQ_INSTS_VALU"], "mean_launch_ms": ktimes[longest],
+                                 "counters_source": prof.get("_source"),
+                                 "note": "fp32 per-(pixel, Gaussian) arithmetic on the vector pipe (MFMA measured slower, DESIGN.md "
+                                         "section 5); the kernel shares its SIMDs with the side-stream optimiser pass while it runs"}
         if split:
             # context for the split optimiser: what the whole Adam step must move vs what of it is left on the critical path
             roofline["optimizer_split"] = {
@@ -650,8 +673,8 @@ def main():
             if "hbm_bytes" in c:
                 e["traffic"] = c["hbm_bytes"]
             if k == "optimizer_early" and ktimes[k] > 0:
-                e["note"] = ("side stream, two launches (waves without tiles of the first 25 % of the row blocks under the forward "
-                             "compositor; the rest of them plus every wave the forward walked nothing of from the start of the backward "
+                e["note"] = ("side stream, two launches (waves without tiles of the first 60 % of the row blocks under the forward "
+                             "compositor, in the kernel's 32-register form; the rest of them plus every wave the forward walked nothing of from the start of the backward "
                              "compositor): ms is the span from the start of the first to the end of the second, idle gap included")
             per_kernel[k] = e
         sh_degree = 3
@@ -679,7 +702,7 @@ def main():
                                                       if getattr(stepper, "_overlap_probe", None) else None)},
             "render_ms_per_frame": res["render_ms"],
             "forward_render_ms_in_train": res["fb"].get("forward_render"), "backward_render_ms_in_train": res["fb"].get("backward_render"),
-            "phase_ms": res["phases"], "step_gpu_span_ms": res["step_spans"], "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline,
+            "phase_ms": res["phases"], "step_gpu_span_ms": res["step_spans"], "scene_stats": stats, "per_kernel": per_kernel, "roofline": roofline, "roofline_valu": roofline_valu,
             "instrumented_pass": (None if res.get("instrumented_ms") is None else {
                 "ms_per_step": res["instrumented_ms"], "steps": args.steps,
                 "note": "`value` / `ms_per_step` are timed with no events in the steps (the product's default, enable_kernel_timings = false); "
