@@ -405,7 +405,8 @@ int gut_optimize_after_bwd(gut_handle h, void* stream, int32_t num_active_featur
  * rewritten) on a side stream owned by the handle, as pure HBM streaming UNDER and beside the VALU-bound compositing kernels of
  * the same iteration.  They are taken by whole 64-row waves, in two launches of a persistent kernel with a small fixed footprint:
  *   1. right away, ordered behind the binning part of the forward only: waves in which no row has a tile
- *      (tiles_count == 0), in the first quarter of the row blocks;
+ *      (tiles_count == 0), in the first 60 % of the row blocks with lazy moments (a 32-register form of the kernel, which
+ *      leaves the forward compositor all of its waves), in the first quarter otherwise;
  *   2. when gut_trace_bwd_ex queues the backward compositor: the remaining waves without tiles and — unsorted variant,
  *      GUT_OPT_EARLY_EXTRA_PERCENT — the waves that have tiles but hold no Gaussian among the list entries the forward
  *      compositor walked (the backward compositor is bounded by the forward's per-tile depth).
