@@ -636,9 +636,13 @@ def main():
                                 "activation row written) UNDER the VALU-bound backward compositor and then beside the pass over the walked "
                                 "waves; it shares the chip by design and is no longer on the step's critical path; alone it runs at the "
                                 "box's device-copy rate (profiles/: optimizer_early_2, PMC pass)")
+        # (always given, for the longer of the two compositors: which of K7 and the side stream's second launch is the step's
+        #  longest launch changes from box to box with the placement of the optimiser state, 0.77 - 0.95 against 0.87 ms)
         roofline_valu = None
-        if longest in VALU_BOUND:
-            roofline["longest_launch_of_the_step"] = longest + " (VALU-bound: see roofline_valu)"
+        roofline["longest_launch_of_the_step"] = longest + (" (VALU-bound: see roofline_valu)" if longest in VALU_BOUND else "")
+        comp = [k for k in VALU_BOUND if ktimes.get(k, -1.0) > 0]
+        if comp:
+            longest = max(comp, key=lambda k: ktimes[k])
             c = pk(longest)
             if "SQ_INSTS_VALU" in c:
                 # wave64 vector instructions per launch (SQ_INSTS_VALU of the tracked PMC pass, same workload) / this run's mean

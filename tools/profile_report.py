@@ -11,7 +11,8 @@ os.makedirs(dst, exist_ok=True)
 # (regex on the demangled kernel name, bench key).  Templated names: k_render<true>(, k_render_backward<false>(, k_sh_adam<true>(
 KEYS = [(r"\bk_project_on_tiles\b", "project"), (r"\bk_scan_wave_sums\b", "scan"), (r"\bk_expand_tiles\b", "expand"), (r"\bk_tile_ranges\b", "ranges"),
         (r"\bk_render(<[^>]*>)?\(", "render"), (r"\bk_render_backward\b", "render_bwd"), (r"\bk_project_backward", "project_bwd"),
-        (r"\bk_sh_adam\b", "optimizer"), (r"\bk_adam_rows_without_gradient\b", "optimizer_early"), (r"onesweep|radix_sort|OneSweep", "sort"),
+        (r"\bk_sh_adam\b", "optimizer"), (r"\bk_adam_rows_without_gradient_narrow\b", "optimizer_early_narrow"),
+        (r"\bk_adam_rows_without_gradient\b", "optimizer_early"), (r"onesweep|radix_sort|OneSweep", "sort"),
         (r"\bk_ssim_|k_photometric", "loss")]
 VALU_ISSUE_NS = 1.16      # one wave64 v_fma_f32 per SIMD every 1.16 ns with >= 2 waves resident (tools/pk_rate.hip, measured)
 SIMDS = 1024
@@ -36,12 +37,18 @@ def _second_half(rows_by_name):
     # the side-stream kernel has two instantiations: <true> (lazy moment decay: the train steps) and <false> (tune_placement's no-op
     # passes, trainers that write their moments every step); when both ran, the steps are the <true> ones
     lazy_steps = any(re.search(r"\bk_adam_rows_without_gradient<true>", kn(name)) for name in rows_by_name)
+    # since the end of round 4 the step's first side-stream launch is the kernel's 32-register form (its own name) and only the
+    # second one is k_adam_rows_without_gradient<true>: one dispatch of each per step
+    narrow = any(re.search(r"\bk_adam_rows_without_gradient_narrow\b", kn(name)) for name in rows_by_name)
     for name, rows in rows_by_name.items():
         kname = kn(name)
         if lazy_steps and re.search(r"\bk_adam_rows_without_gradient<false>", kname):
             continue
+        if re.search(r"\bk_adam_rows_without_gradient_narrow\b", kname):
+            out.extend(rows[-1:])
+            continue
         if re.search(r"\bk_adam_rows_without_gradient\b", kname):
-            out.extend(rows[-2:])   # two launches per step; the run also holds the no-op passes of tune_placement
+            out.extend(rows[-1:] if narrow else rows[-2:])   # (the run also holds the no-op passes of tune_placement)
             continue
         per_step = max(1, len(rows) // PMC_STEPS)
         out.extend(rows[-per_step:] if len(rows) >= PMC_STEPS else rows[len(rows) // 2:])
@@ -66,6 +73,10 @@ def counters(pass_name):
     if "optimizer_early" in acc and all(len(v) == 2 for v in acc["optimizer_early"].values()):
         out["optimizer_early"] = {c: sum(v) for c, v in acc["optimizer_early"].items()}
         out["optimizer_early_2"] = {c: v[1] for c, v in acc["optimizer_early"].items()}
+    elif "optimizer_early" in acc and "optimizer_early_narrow" in acc:
+        out["optimizer_early_2"] = {c: v[-1] for c, v in acc["optimizer_early"].items()}
+        out["optimizer_early"] = {c: v[-1] + acc["optimizer_early_narrow"][c][-1] for c, v in acc["optimizer_early"].items()
+                                  if c in acc["optimizer_early_narrow"]}
     return out
 
 
@@ -84,6 +95,9 @@ def kernel_durations(pass_name):
     if len(acc.get("optimizer_early", [])) == 2:
         out["optimizer_early"] = sum(acc["optimizer_early"])
         out["optimizer_early_2"] = acc["optimizer_early"][1]
+    elif acc.get("optimizer_early") and acc.get("optimizer_early_narrow"):
+        out["optimizer_early_2"] = acc["optimizer_early"][-1]
+        out["optimizer_early"] = acc["optimizer_early"][-1] + acc["optimizer_early_narrow"][-1]
     return out
 
 
@@ -171,8 +185,9 @@ for k in ("project", "expand", "sort", "render", "loss", "render_bwd", "optimize
     L.append(f"| {k} | {g(e, 'duration_ms_SQ_A', '{:.3f}')} | {g(t, 'hbm_bytes', '{:.3e}')} | {g(t, 'hbm_bytes_uncorrected', '{:.3e}')} | "
              f"{g(e, 'SQ_INSTS_VALU', '{:.3e}')} | {g(e, 'valu_issue_frac', '{:.2f}')} | {g(e, 'valu_active_frac', '{:.2f}')} | "
              f"{g(e, 'SQ_INSTS_LDS', '{:.3e}')} | {g(e, 'SQ_LDS_BANK_CONFLICT', '{:.3e}')} | {g(e, 'atomic_GBps', '{:.0f}')} |")
-L += ["", "`optimizer_early` is the side-stream optimiser kernel, launched twice per step: its row is the step's total (both launches, "
-          "run alone here because the PMC passes serialise the kernels), `optimizer_early_2` the second launch.",
+L += ["", "`optimizer_early` is the side-stream optimiser pass, two launches per step (beside K6 the kernel's 32-register form "
+          "`k_adam_rows_without_gradient_narrow`, from K7's start `k_adam_rows_without_gradient<true>`): its row is the step's total (both "
+          "launches, run alone here because the PMC passes serialise the kernels), `optimizer_early_2` the second launch.",
       "", "Top kernels (all launches of the run: warm-up, the 20 timed and the 20 instrumented train steps, 10 render-only frames, the drop-in legs, setup):\n",
       "| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|"]
 for r in rows[:18]:
@@ -190,7 +205,10 @@ if dom:
         d = [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3 for r in csv.DictReader(open(tr[0]))
              if key_of(r["Kernel_Name"]) == ("optimizer_early" if second_launch else dom_key)]
         w0, k0 = int(prof["warmup"]), int(prof["steps"])
-        if second_launch:
+        narrow_first = any(key_of(r["Kernel_Name"]) == "optimizer_early_narrow" for r in csv.DictReader(open(tr[0])))
+        if second_launch and narrow_first:
+            d = d[-k0:]             # the first launch is a kernel of its own: one dispatch of this one per step
+        elif second_launch:
             d = d[-2 * k0:][1::2]   # the stats run ends with the timed steps (--no-sensitivity): two launches each, the second
         else:
             d = d[w0:w0 + k0]       # the headline workload comes first in the run
