@@ -254,10 +254,10 @@ __device__ __forceinline__ uint32_t strip_mask(const StripPlanes& sp, const View
 // Whole-tile termination leaves most of a tile's list untouched (bench frame: 1.28 M of 9.36 M entries are ever staged),
 // so the global sort only groups the (tile | depth, id) pairs by TILE (the two high radix passes; stable, so every tile's
 // entries stay in particle-id order) and the forward compositor orders each tile on demand: before it stages a chunk it
-// selects the next <= 256 entries in (depth bits, list position) order — list position == particle-id order, i.e. exactly
+// selects the next <= 512 entries in (depth bits, list position) order — list position == particle-id order, i.e. exactly
 // the order the full stable sort on (tile | depth) produces — writes their ids to the ordered-id list (the backward and
 // the tests read that) and stages them.  Selection = up to 4 x 8-bit radix select on the depth bits among the entries behind
-// the last one taken, one ordered gather pass, one 512-element bitonic sort in LDS.
+// the last one taken, one gather pass, one 512-element bitonic sort in LDS (lazy_select below).
 constexpr uint32_t kLazyBatch = 512;  // entries ordered per selection: two 256-entry chunks (power of two for the bitonic sort)
 
 struct LazyOrder {
