@@ -138,6 +138,12 @@ __global__ __launch_bounds__(kBlock, 5) void k_render(ViewParams v, RenderConsts
     __shared__ uint16_t s_list[kBlock / 64][kBlock];  // per wave: the staged entries it has to evaluate (index), in list order
     __shared__ StripPlanes s_planes;
     __shared__ LazyOrder s_lazy;
+#ifdef GUT_K6_EXTRA_LDS
+    // DIAGNOSTIC BUILD ONLY: ballast that lowers the number of resident workgroups per CU (what a second staging area would cost)
+    __shared__ float s_ballast6[GUT_K6_EXTRA_LDS / 4];
+    if (threadIdx.x == 0 && v.width < 0) s_ballast6[0] = 1.0f;
+    if (v.width < -1) dist[0] = s_ballast6[threadIdx.x];
+#endif
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;  // (optional) longest lists first
     const uint32_t tid = threadIdx.x;

@@ -5,4 +5,5 @@
 #define GUT_RENDER_GENERAL_TU 1
 #undef GUT_CLOCK_STAMPS   // the diagnostic stamps exist in the default unit only
 #undef GUT_K7_EXTRA_LDS
+#undef GUT_K6_EXTRA_LDS
 #include "gut_render.hip"
